@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's headline metric on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one block of the hot path over one batch of synthetic input: L new samples on
+each of the 64 input channels -> forward FFTs -> 64x64 crossbar multiply-accumulate over 32
+coefficient partitions per filter (4096 independent 262144-tap IRs, 8 GiB of coefficients in
+HBM) -> inverse FFTs -> 64 x L output samples.  Inputs are resident in HBM when the timed region
+starts.  N > 1: the crossbar is sharded by input channel (brutefir_amd/sharding.py), one
+process per GPU, one RCCL reduce-scatter per block; total work is fixed ("strong" scaling).
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+WORKLOADS = {
+    # name: (I, O, L, N, realsize, raw format)
+    "C": (64, 64, 8192, 32, 4, "S24_4LE"),     # BASELINE.json configs[2], the headline
+    "B": (8, 8, 8192, 8, 4, "S24_4LE"),        # configs[1]
+}
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def synth_ir_dev(torch, seed, taps, n_in, device):
+    """white noise * exponential decay, sum|h| = 1/n_in, generated on the GPU"""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    h = torch.randn(taps, generator=g, device=device, dtype=torch.float32)
+    h *= torch.exp(-torch.arange(taps, device=device, dtype=torch.float32) / (taps / 6.0))
+    h /= h.abs().sum() * n_in
+    return h
+
+
+def synth_raw_blocks(torch, n, L, n_ch, device, seed=1234):
+    """n different S24_4LE interleaved blocks of seeded noise at -20 dBFS, in HBM"""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    x = torch.randn(n, L, n_ch, generator=g, device=device, dtype=torch.float32) * 0.1
+    return torch.clamp(torch.round(x * 8388608.0), -8388608, 8388607).to(torch.int32).contiguous()
+
+
+def cpu_baseline(wl, seconds_budget=25.0):
+    """The oracle (a single-threaded port of the reference path, oracle/bf_oracle.c) timed on
+    this box's host cores on a bounded sample of the same workload: a few of the outputs,
+    all inputs, all partitions, a few blocks after the rings are full."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import bforacle as bo
+    I, O, L, N, rs, fmt = wl
+    o_s = min(O, 2)
+    e = bo.Engine(L, N, rs, I, o_s)
+    for c, f in enumerate(bo.interleaved_formats(fmt, I)):
+        e.set_format(0, c, f)
+    for c, f in enumerate(bo.interleaved_formats(fmt, o_s)):
+        e.set_format(1, c, f)
+    e.out_bytes = o_s * L * bo.SAMPLE_FORMATS[fmt][0]
+    rng = np.random.default_rng(99)
+    h = rng.standard_normal(L * N).astype(np.float32 if rs == 4 else np.float64)
+    h *= np.exp(-np.arange(L * N) / (L * N / 6.0))
+    h /= np.abs(h).sum() * I
+    t0 = time.time()
+    for o in range(o_s):
+        for i in range(I):
+            c = e.add_coeff(np.roll(h, 17 * (o * I + i)))
+            e.add_filter(in_ch=[i], out_ch=[o], coeff=c)
+    raw = (rng.standard_normal((L, I)) * 0.1 * 8388608).astype(np.int32)
+    # the cost of a block does not depend on how many ring slots are non-zero: no warm-up
+    e.block(raw)
+    n = 0
+    t1 = time.time()
+    while True:
+        e.block(raw)
+        n += 1
+        el = time.time() - t1
+        if el > seconds_budget * 0.4 or n >= 8:
+            break
+    # per-output cost measured on o_s outputs; the workload's input FFTs are shared by all O
+    sps = o_s * L * n / el
+    return {"value": sps, "unit": "samples/s", "cores": 1, "kind": "port",
+            "sample": "%d of %d outputs x %d inputs x %d partitions of %d taps, %d blocks "
+                      "(input FFTs included), gcc -O2, setup %.1fs"
+                      % (o_s, O, I, N, L, n, t1 - t0)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--workload", default="C", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import brutefir_amd as bf
+    from brutefir_amd import sharding
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with that many ranks" % args.gpus)
+    dist = None
+    backend = os.environ.get("BFHIP_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+
+    wl = WORKLOADS[args.workload]
+    I, O, L, N, rs, fmt = wl
+    fi, ci, fo, co = sharding.shard_crossbar(I, O, world, rank)
+
+    eng = bf.Engine(L, N, rs, ci, O, device=dev_index)
+    infmts = bf.interleaved_formats(fmt, I)
+    for c in range(ci):
+        eng.set_format(bf.IN, c, infmts[fi + c])
+    for c, f in enumerate(bf.interleaved_formats(fmt, O)):
+        eng.set_format(bf.OUT, c, f)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    taps = L * N
+    for o in range(O):
+        for i in range(fi, fi + ci):
+            h = synth_ir_dev(torch, 4321 + o * I + i, taps, I, device)
+            c = eng.add_coeff_dev(h, taps)
+            eng.add_filter(in_ch=[i - fi], out_ch=[o], coeff=c)
+    torch.cuda.synchronize()
+    eng.finalize()
+    alg = eng.algorithmic_bytes()
+
+    n_pool = 4
+    raw_in = synth_raw_blocks(torch, n_pool, L, I, device)
+    raw_out = torch.zeros(L, O, dtype=torch.int32, device=device)
+    if world > 1:
+        z_part = torch.zeros(O, L, 2, dtype=torch.float32, device=device)
+        z_loc = torch.zeros(co, L, 2, dtype=torch.float32, device=device)
+
+    def step(k):
+        src = raw_in[k % n_pool]
+        if world == 1:
+            eng.block_dev(src, raw_out)
+        else:
+            eng.inputs_dev(src)
+            eng.mac_dev(z_part)
+            sharding.mixdown(z_part, z_loc)
+            eng.outputs_dev(z_loc, fo, co, raw_out)
+            eng.advance()
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    fence()
+    if world == 1:
+        eng.enable_timing(True)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k)
+    fence()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    status = eng.sync()
+
+    if rank == 0:
+        ms = el * 1e3 / args.steps
+        value = O * L * args.steps / el
+        out = {
+            "metric": "filtered samples/sec (64ch x 256k-tap overlap-save)" if args.workload == "C"
+                      else "filtered samples/sec",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32" if rs == 4 else "f64",
+            "data": "synthetic (seeded noise PCM, seeded decaying-noise IRs)",
+            "config": {"workload": "%d-in/%d-out full crossbar, %d taps (%d x %d partitions), "
+                                   "%s, %d filters" % (I, O, L * N, L, N, fmt, I * O),
+                       "baseline_config": "configs[2]" if args.workload == "C" else "configs[1]",
+                       "parallelism": "input-sharded x%d + reduce-scatter" % world if world > 1
+                                      else "single GPU",
+                       "status_bits": status},
+            "hbm_gbs_algorithmic": alg["block"] / (ms * 1e-3) / 1e9 if world == 1 else None,
+        }
+        if world == 1:
+            tm = eng.timing()
+            mac_s = tm["mac_ms"] * 1e-3
+            ach = alg["mac"] / mac_s / 1e9 if mac_s > 0 else None
+            out["roofline"] = {"bound": "hbm", "kernel": "mac_xbar_kernel", "achieved": ach,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": None,
+                               "algorithmic_bytes_per_launch": alg["mac"],
+                               "avg_launch_ms": tm["mac_ms"], "launches": tm["launches"],
+                               "fft_in_ms": tm["fft_in_ms"], "ifft_out_ms": tm["ifft_out_ms"]}
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(wl)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

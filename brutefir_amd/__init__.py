@@ -1,0 +1,293 @@
+"""brutefir_amd -- MI355X-native replacement for BruteFIR's filter path.
+
+The product is `libbfhip.so` (HIP kernels + a plain C ABI, `include/bfhip.h`); the C host
+(`bfrun`/`bfconf`, bfio and bflogic modules) binds to it directly.  This
+package is the thin Python binding used by tests/ and bench.py: it mirrors the C ABI one to
+one and adds nothing.  There is no CPU path: if the library or a HIP device is missing every
+call raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libbfhip.so")
+
+IN, OUT = 0, 1
+ST_NONFINITE, ST_SAFETY = 1, 2
+
+
+class BfhipError(RuntimeError):
+    pass
+
+
+class Overflow(C.Structure):
+    """struct bfoverflow (bfmod.h:99-104)"""
+    _fields_ = [("n_overflows", C.c_uint), ("intlargest", C.c_int32),
+                ("largest", C.c_double), ("max", C.c_double)]
+
+    def astuple(self):
+        return (self.n_overflows, self.intlargest, self.largest, self.max)
+
+
+class Format(C.Structure):
+    """struct sample_format + struct buffer_format (dai.h:21-34)"""
+    _fields_ = [("isfloat", C.c_int), ("swap", C.c_int), ("bytes", C.c_int),
+                ("sbytes", C.c_int), ("scale", C.c_double),
+                ("sample_spacing", C.c_int), ("byte_offset", C.c_int)]
+
+
+# bfconf.c:358-480 (the _NE macro formats are resolved by the host before they get here)
+SAMPLE_FORMATS = {
+    "S8": (1, 1, 0, True),
+    "S16_LE": (2, 2, 0, True), "S16_BE": (2, 2, 0, False),
+    "S24_LE": (3, 3, 0, True), "S24_BE": (3, 3, 0, False),
+    "S24_4LE": (4, 3, 0, True), "S24_4BE": (4, 3, 0, False),
+    "S32_LE": (4, 4, 0, True), "S32_BE": (4, 4, 0, False),
+    "FLOAT_LE": (4, 4, 1, True), "FLOAT_BE": (4, 4, 1, False),
+    "FLOAT64_LE": (8, 8, 1, True), "FLOAT64_BE": (8, 8, 1, False),
+}
+
+
+def make_format(name, sample_spacing=1, byte_offset=0):
+    nbytes, sbytes, isfloat, le = SAMPLE_FORMATS[name]
+    scale = 1.0 if isfloat else 1.0 / float(1 << (8 * sbytes - 1))
+    return Format(isfloat, 0 if le else 1, nbytes, sbytes, scale, sample_spacing, byte_offset)
+
+
+def interleaved_formats(name, n_channels):
+    """buffer_format of an interleaved device with n_channels open (dai.c:537-576)"""
+    nbytes = SAMPLE_FORMATS[name][0]
+    return [make_format(name, n_channels, c * nbytes) for c in range(n_channels)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libbfhip.so.  Raises if it has not been built -- never falls back to anything."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BfhipError("%s is missing: build it with `python -m brutefir_amd.build` "
+                         "(there is no CPU fallback)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, ci, cd = C.c_void_p, C.c_int, C.c_double
+    ip, dp = C.POINTER(ci), C.POINTER(cd)
+    L.bfhip_last_error.restype = C.c_char_p
+    L.bfhip_version.restype = C.c_char_p
+    L.bfhip_engine_create.restype = vp
+    L.bfhip_engine_create.argtypes = [ci] * 6
+    L.bfhip_engine_destroy.argtypes = [vp]
+    L.bfhip_engine_set_format.argtypes = [vp, ci, ci, C.POINTER(Format)]
+    L.bfhip_engine_set_safety_limit.argtypes = [vp, cd]
+    L.bfhip_engine_enable_dither.argtypes = [vp, ip, ci, ci, ci]
+    L.bfhip_engine_add_coeff.argtypes = [vp, vp, ci, cd, ci]
+    L.bfhip_engine_add_coeff_dev.argtypes = [vp, vp, ci, cd, ci]
+    L.bfhip_engine_update_coeff_block.argtypes = [vp, ci, ci, vp]
+    L.bfhip_engine_add_filter.argtypes = [vp, ci, ip, dp, ci, ip, dp, ci, ip, dp, ci, ci, ci]
+    L.bfhip_engine_finalize.argtypes = [vp]
+    L.bfhip_engine_set_coeff.argtypes = [vp, ci, ci]
+    L.bfhip_engine_set_delayblocks.argtypes = [vp, ci, ci]
+    L.bfhip_engine_set_scale.argtypes = [vp, ci, ci, ci, cd]
+    L.bfhip_engine_set_fscale.argtypes = [vp, ci, ci, cd]
+    L.bfhip_engine_block.argtypes = [vp, vp, vp, C.POINTER(Overflow)]
+    L.bfhip_engine_block_dev.argtypes = [vp, vp, vp]
+    L.bfhip_engine_sync.argtypes = [vp]
+    L.bfhip_engine_inputs_dev.argtypes = [vp, vp]
+    L.bfhip_engine_mac_dev.argtypes = [vp, vp]
+    L.bfhip_engine_outputs_dev.argtypes = [vp, vp, ci, ci, vp]
+    L.bfhip_engine_advance.argtypes = [vp]
+    L.bfhip_engine_set_stream.argtypes = [vp, vp]
+    L.bfhip_engine_get_overflow.argtypes = [vp, ci, C.POINTER(Overflow)]
+    L.bfhip_engine_reset_overflow.argtypes = [vp]
+    L.bfhip_engine_blockcounter.restype = C.c_uint
+    L.bfhip_engine_blockcounter.argtypes = [vp]
+    L.bfhip_engine_enable_timing.argtypes = [vp, ci]
+    L.bfhip_engine_get_timing.argtypes = [vp, dp]
+    L.bfhip_engine_algorithmic_bytes.argtypes = [vp, dp]
+    L.bfhip_engine_read_output_spectrum.argtypes = [vp, ci, vp]
+    L.bfhip_engine_read_ring_slot.argtypes = [vp, ci, ci, vp]
+    _lib = L
+    return L
+
+
+def _check(r):
+    if r < 0:
+        raise BfhipError("bfhip error %d: %s" % (r, lib().bfhip_last_error().decode()))
+    return r
+
+
+def _iarr(v):
+    return (C.c_int * max(len(v), 1))(*v)
+
+
+def _darr(v):
+    return (C.c_double * max(len(v), 1))(*v)
+
+
+def _ptr(x):
+    """host numpy array, torch tensor (host or device) or raw integer address -> void*"""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    return x.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One filter process worth of device state (bfhip_engine)."""
+
+    def __init__(self, length, n_blocks, realsize, n_in, n_out, device=0):
+        self.L, self.N, self.rs, self.n_in, self.n_out = length, n_blocks, realsize, n_in, n_out
+        self.dt = np.float32 if realsize == 4 else np.float64
+        self.cdt = np.complex64 if realsize == 4 else np.complex128
+        self.h = lib().bfhip_engine_create(device, length, n_blocks, realsize, n_in, n_out)
+        if not self.h:
+            raise BfhipError(lib().bfhip_last_error().decode())
+        self.out_bytes = n_out * length * realsize
+        self.in_bytes = n_in * length * realsize
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().bfhip_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    # ---- construction
+    def set_format(self, io, ch, fmt):
+        _check(lib().bfhip_engine_set_format(self.h, io, ch, C.byref(fmt)))
+
+    def set_interleaved(self, io, name):
+        n = self.n_in if io == IN else self.n_out
+        for c, f in enumerate(interleaved_formats(name, n)):
+            self.set_format(io, c, f)
+        nbytes = n * self.L * SAMPLE_FORMATS[name][0]
+        if io == IN:
+            self.in_bytes = nbytes
+        else:
+            self.out_bytes = nbytes
+
+    def set_safety_limit(self, v):
+        _check(lib().bfhip_engine_set_safety_limit(self.h, v))
+
+    def enable_dither(self, channels, sample_rate, max_size=0):
+        _check(lib().bfhip_engine_enable_dither(self.h, _iarr(list(channels)), len(channels),
+                                                sample_rate, max_size))
+
+    def add_coeff(self, taps, scale=1.0, n_blocks=0):
+        taps = np.ascontiguousarray(taps, self.dt)
+        return _check(lib().bfhip_engine_add_coeff(self.h, _ptr(taps), len(taps), scale, n_blocks))
+
+    def add_coeff_dev(self, taps_dev, n_taps, scale=1.0, n_blocks=0):
+        return _check(lib().bfhip_engine_add_coeff_dev(self.h, _ptr(taps_dev), n_taps, scale,
+                                                       n_blocks))
+
+    def update_coeff_block(self, coeff, block, taps):
+        taps = np.ascontiguousarray(taps, self.dt)
+        assert len(taps) == self.L
+        _check(lib().bfhip_engine_update_coeff_block(self.h, coeff, block, _ptr(taps)))
+
+    def add_filter(self, in_ch=(), in_scale=None, in_f=(), in_fscale=None, out_ch=(),
+                   out_scale=None, coeff=-1, delayblocks=0, crossfade=False):
+        in_scale = [1.0] * len(in_ch) if in_scale is None else list(in_scale)
+        in_fscale = [1.0] * len(in_f) if in_fscale is None else list(in_fscale)
+        out_scale = [1.0] * len(out_ch) if out_scale is None else list(out_scale)
+        return _check(lib().bfhip_engine_add_filter(
+            self.h, len(in_ch), _iarr(list(in_ch)), _darr(in_scale),
+            len(in_f), _iarr(list(in_f)), _darr(in_fscale),
+            len(out_ch), _iarr(list(out_ch)), _darr(out_scale),
+            coeff, delayblocks, int(crossfade)))
+
+    def finalize(self):
+        _check(lib().bfhip_engine_finalize(self.h))
+
+    # ---- run-time control
+    def set_coeff(self, f, c):
+        _check(lib().bfhip_engine_set_coeff(self.h, f, c))
+
+    def set_delayblocks(self, f, d):
+        _check(lib().bfhip_engine_set_delayblocks(self.h, f, d))
+
+    def set_scale(self, f, io, idx, v):
+        _check(lib().bfhip_engine_set_scale(self.h, f, io, idx, v))
+
+    def set_fscale(self, f, idx, v):
+        _check(lib().bfhip_engine_set_fscale(self.h, f, idx, v))
+
+    # ---- per block
+    def block(self, rawin, overflow=None):
+        """host buffers in / out; returns (status bits, raw output bytes)"""
+        rawin = np.ascontiguousarray(rawin).view(np.uint8).ravel()
+        assert rawin.size >= self.in_bytes, (rawin.size, self.in_bytes)
+        out = np.zeros(self.out_bytes, np.uint8)
+        st = _check(lib().bfhip_engine_block(self.h, _ptr(rawin), _ptr(out), overflow))
+        return st, out
+
+    def block_dev(self, rawin_dev, rawout_dev):
+        _check(lib().bfhip_engine_block_dev(self.h, _ptr(rawin_dev), _ptr(rawout_dev)))
+
+    def sync(self):
+        return _check(lib().bfhip_engine_sync(self.h))
+
+    def inputs_dev(self, rawin_dev):
+        _check(lib().bfhip_engine_inputs_dev(self.h, _ptr(rawin_dev)))
+
+    def mac_dev(self, z_dev):
+        _check(lib().bfhip_engine_mac_dev(self.h, _ptr(z_dev)))
+
+    def outputs_dev(self, z_dev, first, count, rawout_dev):
+        _check(lib().bfhip_engine_outputs_dev(self.h, _ptr(z_dev), first, count, _ptr(rawout_dev)))
+
+    def advance(self):
+        _check(lib().bfhip_engine_advance(self.h))
+
+    def set_stream(self, hip_stream):
+        _check(lib().bfhip_engine_set_stream(self.h, C.c_void_p(hip_stream)))
+
+    def overflow(self, ch):
+        of = Overflow()
+        _check(lib().bfhip_engine_get_overflow(self.h, ch, C.byref(of)))
+        return of
+
+    def reset_overflow(self):
+        _check(lib().bfhip_engine_reset_overflow(self.h))
+
+    @property
+    def blockcounter(self):
+        return lib().bfhip_engine_blockcounter(self.h)
+
+    # ---- measurement / debug
+    def enable_timing(self, on=True):
+        _check(lib().bfhip_engine_enable_timing(self.h, int(on)))
+
+    def timing(self):
+        ms = (C.c_double * 4)()
+        _check(lib().bfhip_engine_get_timing(self.h, ms))
+        return {"fft_in_ms": ms[0], "mac_ms": ms[1], "ifft_out_ms": ms[2], "launches": int(ms[3])}
+
+    def algorithmic_bytes(self):
+        b = (C.c_double * 2)()
+        _check(lib().bfhip_engine_algorithmic_bytes(self.h, b))
+        return {"block": b[0], "mac": b[1]}
+
+    def output_spectrum(self, ch):
+        """packed spectrum of output ch: element 0 = (DC, Nyquist), element k = bin k"""
+        z = np.empty(self.L, self.cdt)
+        _check(lib().bfhip_engine_read_output_spectrum(self.h, ch, _ptr(z)))
+        return z
+
+    def ring_slot(self, ch, slot):
+        z = np.empty(self.L, self.cdt)
+        _check(lib().bfhip_engine_read_ring_slot(self.h, ch, slot, _ptr(z)))
+        return z
+
+
+def device_count():
+    return lib().bfhip_device_count()

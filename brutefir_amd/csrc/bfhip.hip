@@ -1,0 +1,849 @@
+// bfhip.hip -- host side of the engine + the C ABI of include/bfhip.h.
+//
+// What the reference's filter_process() does with host buffers and a chain of convolver_*
+// calls per filter (bfrun.c:1493-2008) is turned into a static device plan here:
+//   * every input channel owns one ring of its last N spectra in HBM (the reference keeps one
+//     ring per filter, bfrun.c:1273-1287; filters that only scale a single input share the
+//     input's ring and carry their scale in the plan -> the ring is read once per output
+//     group instead of once per filter);
+//   * every output group owns a list of (ring, delay) entries with up to 8 filter terms each;
+//   * a block is three launches: fft_in (K1), mac_xbar (K2), ifft_out (K3).
+// The integer bookkeeping (slot = blockcounter mod N, delay clamp, cblocks truncation,
+// warm-up count) follows bfrun.c:1566-1600,1745-1746 literally.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/bfhip.h"
+#include "kernels.h"
+
+using namespace bfhip;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess)                                                             \
+            return fail(BFHIP_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                        __FILE__, __LINE__);                                              \
+    } while (0)
+
+int ilog2(int v) {
+    int o = 0;
+    while ((1 << o) < v) o++;
+    return ((1 << o) == v) ? o : -1;
+}
+
+struct Coeff {
+    int n_blocks = 0;
+    void *d_H = nullptr;     // [n_blocks][L] packed spectra
+};
+
+struct Filter {
+    std::vector<int> in_ch, in_f, out_ch;
+    std::vector<double> in_scale, in_fscale, out_scale;
+    int coeff = -1, delayblocks = 0, crossfade = 0;
+    int prevcoeff = -1;
+};
+
+constexpr int MAX_TIMED = 4096;
+
+}  // namespace
+
+struct bfhip_engine {
+    int device = 0;
+    int L = 0, N = 0, rs = 4, log2L = 0;
+    int n_ch[2] = {0, 0};
+    std::vector<bfhip_format> fmt[2];
+    double safety_limit = 0.0;
+    std::vector<Coeff> coeffs;
+    std::vector<Filter> filters;
+    bool finalized = false, plan_dirty = true;
+    unsigned int blockcounter = 0;
+    unsigned long long blocks_done = 0;      // since creation (procblocks analogue)
+
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+
+    // device state
+    void *d_tw = nullptr;          // [2L] complex
+    void *d_prev = nullptr;        // [n_in][L] real
+    void *d_ring = nullptr;        // [n_in][N][L] complex
+    DevFormat *d_fmt[2] = {nullptr, nullptr};
+    DevOverflow *d_over = nullptr;
+    int *d_status = nullptr;
+    int *d_bad = nullptr;
+    void *d_Zp = nullptr;          // [n_chunks][n_out_padded][L] complex
+    size_t zp_bytes = 0;
+    void *d_entries = nullptr;
+    size_t entries_cap = 0;
+    ChunkRange *d_chunks = nullptr;
+    size_t chunks_cap = 0;
+    uint8_t *d_rawin = nullptr, *d_rawout = nullptr;
+    size_t raw_bytes[2] = {0, 0};
+    void *d_taps = nullptr;
+    size_t taps_cap = 0;
+
+    // plan geometry
+    int n_groups = 0, n_out_padded = 0, n_chunks = 1, n_tiles = 1, mac_threads = 256;
+    int n_entries = 0;
+    double alg_bytes_total = 0, alg_bytes_mac = 0;
+
+    // timing
+    bool timing = false;
+    std::vector<hipEvent_t> ev;    // 4 per block: before K1, after K1, after K2, after K3
+    int ev_used = 0;
+
+    size_t csize() const { return (size_t)2 * rs; }     // bytes per complex
+};
+
+namespace {
+
+// ---------------------------------------------------------------- template dispatch
+
+#define DISPATCH_LOG2L(T, FN, ...)                        \
+    switch (e->log2L) {                                   \
+    case 6: FN<T, 6>(__VA_ARGS__); break;                 \
+    case 7: FN<T, 7>(__VA_ARGS__); break;                 \
+    case 8: FN<T, 8>(__VA_ARGS__); break;                 \
+    case 9: FN<T, 9>(__VA_ARGS__); break;                 \
+    case 10: FN<T, 10>(__VA_ARGS__); break;               \
+    case 11: FN<T, 11>(__VA_ARGS__); break;               \
+    case 12: FN<T, 12>(__VA_ARGS__); break;               \
+    case 13: FN<T, 13>(__VA_ARGS__); break;               \
+    default: break;                                       \
+    }
+
+#define DISPATCH(FN, ...)                                                   \
+    do {                                                                    \
+        if (e->rs == 4) { DISPATCH_LOG2L(float, FN, __VA_ARGS__) }          \
+        else { DISPATCH_LOG2L(double, FN, __VA_ARGS__) }                    \
+    } while (0)
+
+template <typename K> hipError_t allow_lds(K kernel, size_t bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+template <typename T, int LOG2L>
+void launch_fft_in(bfhip_engine *e, const uint8_t *raw, int slot, hipError_t *err) {
+    constexpr int NT = fft_threads(LOG2L);
+    const size_t lds = sizeof(c2<T>) << LOG2L;
+    auto k = fft_in_kernel<T, LOG2L>;
+    *err = allow_lds(k, lds);
+    if (*err != hipSuccess) return;
+    hipLaunchKernelGGL(k, dim3(e->n_ch[0]), dim3(NT), lds, e->stream, raw, e->d_fmt[0],
+                       (T *)e->d_prev, (c2<T> *)e->d_ring, (const c2<T> *)e->d_tw, e->N, slot);
+    *err = hipGetLastError();
+}
+
+template <typename T, int LOG2L>
+void launch_coeff_prep(bfhip_engine *e, const void *taps, int n_taps, double scale, void *H,
+                       int n_blocks, hipError_t *err) {
+    constexpr int NT = fft_threads(LOG2L);
+    const size_t lds = sizeof(c2<T>) << LOG2L;
+    auto k = coeff_prep_kernel<T, LOG2L>;
+    *err = allow_lds(k, lds);
+    if (*err != hipSuccess) return;
+    hipLaunchKernelGGL(k, dim3(n_blocks), dim3(NT), lds, e->stream, (const T *)taps, n_taps,
+                       (T)scale, (c2<T> *)H, (const c2<T> *)e->d_tw, e->d_bad);
+    *err = hipGetLastError();
+}
+
+template <typename T, int LOG2L>
+void launch_ifft_out(bfhip_engine *e, const void *Zp, size_t chunk_stride, int n_chunks,
+                     int first, int count, uint8_t *raw, hipError_t *err) {
+    constexpr int NT = fft_threads(LOG2L);
+    const size_t lds = sizeof(c2<T>) << LOG2L;
+    auto k = ifft_out_kernel<T, LOG2L>;
+    *err = allow_lds(k, lds);
+    if (*err != hipSuccess) return;
+    hipLaunchKernelGGL(k, dim3(count), dim3(NT), lds, e->stream, (const c2<T> *)Zp, chunk_stride,
+                       n_chunks, first, e->d_fmt[1], e->d_over, (const unsigned char *)nullptr,
+                       raw, (T *)nullptr, (const c2<T> *)e->d_tw, e->safety_limit, e->d_status);
+    *err = hipGetLastError();
+}
+
+template <typename T>
+void launch_mac(bfhip_engine *e, void *Zp, hipError_t *err) {
+    const int n_tc = e->n_tiles * e->n_chunks;
+    const int tc8 = (n_tc + 7) / 8;
+    const int grid = tc8 * e->n_groups * 8;
+    const unsigned long long age64 = std::min<unsigned long long>(e->blocks_done + 1, (unsigned long long)e->N);
+    hipLaunchKernelGGL(mac_xbar_kernel<T>, dim3(grid), dim3(e->mac_threads), 0, e->stream,
+                       (const MacEntry<T> *)e->d_entries, (const ChunkRange *)e->d_chunks,
+                       (c2<T> *)Zp, e->L, e->n_out_padded, e->n_groups, e->n_chunks, n_tc,
+                       e->blockcounter, (int)age64);
+    *err = hipGetLastError();
+}
+
+template <typename T>
+void launch_sum(bfhip_engine *e, const void *Zp, void *Z, hipError_t *err) {
+    const size_t n_per_chunk = (size_t)e->n_out_padded * e->L;
+    const size_t n_valid = (size_t)e->n_ch[1] * e->L;
+    const int grid = (int)((n_valid + 255) / 256);
+    hipLaunchKernelGGL(sum_partials_kernel<T>, dim3(grid), dim3(256), 0, e->stream,
+                       (const c2<T> *)Zp, (c2<T> *)Z, n_per_chunk, n_valid, e->n_chunks);
+    *err = hipGetLastError();
+}
+
+// ---------------------------------------------------------------- plan
+
+int clamp_delay(const bfhip_engine *e, int d) {          // bfrun.c:1579-1584
+    if (d < 0) return 0;
+    if (d > e->N - 1) return e->N - 1;
+    return d;
+}
+
+int cblocks_of(const bfhip_engine *e, int coeff, int delay) {   // bfrun.c:1585-1591
+    if (coeff < 0 || e->coeffs[coeff].n_blocks > e->N - delay) return e->N - delay;
+    return e->coeffs[coeff].n_blocks;
+}
+
+template <typename T>
+int build_plan_t(bfhip_engine *e) {
+    const int O = e->n_ch[1];
+    e->n_groups = (O + OG - 1) / OG;
+    e->n_out_padded = e->n_groups * OG;
+    std::vector<std::vector<MacEntry<T>>> per_group(e->n_groups);
+    std::vector<std::map<std::pair<int, int>, std::vector<int>>> index(e->n_groups);
+    double bytes_H = 0, bytes_ring = 0;
+    std::vector<char> ring_used((size_t)e->n_ch[0] * e->N, 0);
+
+    for (size_t fi = 0; fi < e->filters.size(); fi++) {
+        const Filter &f = e->filters[fi];
+        if (f.in_ch.size() != 1 || !f.in_f.empty()) {
+            return fail(BFHIP_EINVAL, "filter %zu: only single-input filters are supported by this "
+                        "build of the device plan", fi);
+        }
+        if (f.coeff >= (int)e->coeffs.size()) return fail(BFHIP_EINVAL, "filter %zu: bad coeff", fi);
+        const int ch = f.in_ch[0];
+        const int delay = clamp_delay(e, f.delayblocks);
+        const int P = f.coeff < 0 ? 1 : cblocks_of(e, f.coeff, delay);
+        const double s_in = f.in_scale[0] * e->fmt[0][ch].scale;          // bfrun.c:1664
+        for (int p = 0; p < P; p++) ring_used[(size_t)ch * e->N + ((p + delay) % e->N)] = 1;
+        for (size_t oi = 0; oi < f.out_ch.size(); oi++) {
+            const int o = f.out_ch[oi];
+            const int g = o / OG, j = o % OG;
+            const double s_out = f.out_scale[oi] / e->fmt[1][o].scale;    // bfrun.c:1850
+            auto &slots = index[g][{ch, delay}];
+            int ei = -1;
+            for (int cand : slots) {
+                if (per_group[g][cand].term[j].kind == TERM_NONE) { ei = cand; break; }
+            }
+            if (ei < 0) {
+                MacEntry<T> ne;
+                memset(&ne, 0, sizeof(ne));
+                ne.ring = (const c2<T> *)e->d_ring + (size_t)ch * e->N * e->L;
+                ne.R = e->N;
+                ne.delay = delay;
+                for (int q = 0; q < OG; q++) ne.term[q].kind = TERM_NONE;
+                per_group[g].push_back(ne);
+                ei = (int)per_group[g].size() - 1;
+                slots.push_back(ei);
+            }
+            MacTerm<T> &tm = per_group[g][ei].term[j];
+            tm.kind = f.coeff < 0 ? TERM_DIRAC : TERM_COEFF;
+            tm.H = f.coeff < 0 ? nullptr : (const c2<T> *)e->coeffs[f.coeff].d_H;
+            tm.P = P;
+            tm.scale = (T)(s_in * s_out);
+            per_group[g][ei].maxP = std::max(per_group[g][ei].maxP, P);
+            if (f.coeff >= 0) bytes_H += (double)P * e->L * sizeof(c2<T>);
+        }
+    }
+
+    // chunking: enough workgroups to fill 256 CUs several times over
+    e->mac_threads = std::min(256, std::max(64, e->L / (int)(16 / sizeof(c2<T>))));
+    const int bins_per_wg = e->mac_threads * (int)(16 / sizeof(c2<T>));
+    e->n_tiles = (e->L + bins_per_wg - 1) / bins_per_wg;
+    size_t max_entries = 1;
+    for (auto &v : per_group) max_entries = std::max(max_entries, v.size());
+    const int target_wgs = 4096;
+    int S = (target_wgs + e->n_tiles * e->n_groups - 1) / (e->n_tiles * e->n_groups);
+    S = std::max(1, std::min<int>(S, (int)max_entries));
+    e->n_chunks = S;
+
+    std::vector<MacEntry<T>> flat;
+    std::vector<ChunkRange> chunks((size_t)e->n_groups * S);
+    for (int g = 0; g < e->n_groups; g++) {
+        const auto &v = per_group[g];
+        long total = 0;
+        for (auto &en : v) total += en.maxP;
+        const int base = (int)flat.size();
+        size_t pos = 0;
+        long acc = 0;
+        for (int c = 0; c < S; c++) {
+            ChunkRange cr;
+            cr.begin = base + (int)pos;
+            const long want = (total * (c + 1) + S - 1) / S;
+            while (pos < v.size() && (acc < want || c == S - 1)) { acc += v[pos].maxP; pos++; }
+            cr.end = base + (int)pos;
+            chunks[(size_t)g * S + c] = cr;
+        }
+        flat.insert(flat.end(), v.begin(), v.end());
+    }
+    e->n_entries = (int)flat.size();
+
+    // upload
+    const size_t eb = std::max<size_t>(flat.size(), 1) * sizeof(MacEntry<T>);
+    if (eb > e->entries_cap) {
+        if (e->d_entries) (void)hipFree(e->d_entries);
+        HIPCHK(hipMalloc(&e->d_entries, eb));
+        e->entries_cap = eb;
+    }
+    const size_t cb = chunks.size() * sizeof(ChunkRange);
+    if (cb > e->chunks_cap) {
+        if (e->d_chunks) (void)hipFree(e->d_chunks);
+        HIPCHK(hipMalloc((void **)&e->d_chunks, cb));
+        e->chunks_cap = cb;
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (!flat.empty()) HIPCHK(hipMemcpy(e->d_entries, flat.data(), flat.size() * sizeof(MacEntry<T>), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_chunks, chunks.data(), cb, hipMemcpyHostToDevice));
+    const size_t zb = (size_t)S * e->n_out_padded * e->L * sizeof(c2<T>);
+    if (zb > e->zp_bytes) {
+        if (e->d_Zp) (void)hipFree(e->d_Zp);
+        HIPCHK(hipMalloc(&e->d_Zp, zb));
+        e->zp_bytes = zb;
+    }
+
+    // algorithmic bytes per block, SURVEY 8(d): C*(F*P + U*P + U + O) + (I+O)*L*s_raw
+    const double C = (double)e->L * sizeof(c2<T>);
+    for (char u : ring_used) bytes_ring += u ? C : 0;
+    double raw = 0;
+    for (int io = 0; io < 2; io++)
+        for (auto &f : e->fmt[io]) raw += (double)e->L * f.bytes;
+    e->alg_bytes_mac = bytes_H + bytes_ring + C * O;
+    e->alg_bytes_total = e->alg_bytes_mac + C * e->n_ch[0] + raw;
+    e->plan_dirty = false;
+    return BFHIP_OK;
+}
+
+int build_plan(bfhip_engine *e) {
+    return e->rs == 4 ? build_plan_t<float>(e) : build_plan_t<double>(e);
+}
+
+size_t raw_extent(const std::vector<bfhip_format> &v, int L) {
+    size_t m = 0;
+    for (auto &f : v) {
+        const size_t end = (size_t)f.byte_offset + ((size_t)(L - 1) * f.sample_spacing + 1) * f.bytes;
+        m = std::max(m, end);
+    }
+    return m;
+}
+
+DevFormat to_dev(const bfhip_format &f) {
+    DevFormat d;
+    d.isfloat = f.isfloat; d.swap = f.swap; d.bytes = f.bytes; d.sbytes = f.sbytes;
+    d.sample_spacing = f.sample_spacing; d.byte_offset = f.byte_offset;
+    return d;
+}
+
+double overflow_max(const bfhip_format &f) {             // bfrun.c:2270-2277
+    return f.isfloat ? 1.0 : (double)((uint64_t)1 << ((f.sbytes << 3) - 1)) - 1;
+}
+
+int upload_formats(bfhip_engine *e) {
+    for (int io = 0; io < 2; io++) {
+        std::vector<DevFormat> d;
+        for (auto &f : e->fmt[io]) d.push_back(to_dev(f));
+        if (!d.empty()) HIPCHK(hipMemcpy(e->d_fmt[io], d.data(), d.size() * sizeof(DevFormat), hipMemcpyHostToDevice));
+    }
+    return BFHIP_OK;
+}
+
+int check_format(const bfhip_format *f) {
+    if (f->isfloat) {
+        if (f->bytes != 4 && f->bytes != 8) return 0;
+    } else if (f->bytes < 1 || f->bytes > 4 || f->sbytes < 1 || f->sbytes > f->bytes) {
+        return 0;
+    }
+    return f->sample_spacing >= 1 && f->byte_offset >= 0;
+}
+
+int record(bfhip_engine *e, int idx) {
+    if (!e->timing || e->ev_used >= MAX_TIMED) return BFHIP_OK;
+    HIPCHK(hipEventRecord(e->ev[(size_t)e->ev_used * 4 + idx], e->stream));
+    return BFHIP_OK;
+}
+
+int ensure_ready(bfhip_engine *e) {
+    if (!e->finalized) return fail(BFHIP_ESTATE, "engine not finalized");
+    HIPCHK(hipSetDevice(e->device));
+    if (e->plan_dirty) return build_plan(e);
+    return BFHIP_OK;
+}
+
+int do_inputs(bfhip_engine *e, const void *rawin_dev) {
+    hipError_t err = hipSuccess;
+    const int slot = (int)(e->blockcounter % (unsigned int)e->N);
+    DISPATCH(launch_fft_in, e, (const uint8_t *)rawin_dev, slot, &err);
+    if (err != hipSuccess) return fail(BFHIP_EHIP, "fft_in launch: %s", hipGetErrorString(err));
+    return BFHIP_OK;
+}
+
+int do_mac(bfhip_engine *e, void *Zp) {
+    hipError_t err = hipSuccess;
+    if (e->rs == 4) launch_mac<float>(e, Zp, &err); else launch_mac<double>(e, Zp, &err);
+    if (err != hipSuccess) return fail(BFHIP_EHIP, "mac launch: %s", hipGetErrorString(err));
+    return BFHIP_OK;
+}
+
+int do_outputs(bfhip_engine *e, const void *Zp, size_t chunk_stride, int n_chunks, int first,
+               int count, void *rawout_dev) {
+    hipError_t err = hipSuccess;
+    if (count <= 0) return BFHIP_OK;
+    DISPATCH(launch_ifft_out, e, Zp, chunk_stride, n_chunks, first, count, (uint8_t *)rawout_dev, &err);
+    if (err != hipSuccess) return fail(BFHIP_EHIP, "ifft_out launch: %s", hipGetErrorString(err));
+    return BFHIP_OK;
+}
+
+void advance(bfhip_engine *e) {
+    e->blockcounter++;                                   // bfrun.c:2034 (unsigned wrap)
+    e->blocks_done++;
+}
+
+}  // namespace
+
+// ==================================================================== C ABI
+
+extern "C" {
+
+const char *bfhip_last_error(void) { return g_err.c_str(); }
+const char *bfhip_version(void) { return "bfhip 0.1 (gfx950)"; }
+
+int bfhip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+bfhip_engine *bfhip_engine_create(int device, int length, int n_blocks, int realsize,
+                                  int n_in, int n_out) {
+    if (realsize != 4 && realsize != 8) { fail(BFHIP_EINVAL, "Invalid real size %d.", realsize); return nullptr; }
+    const int lg = ilog2(length);
+    if (lg < 6 || lg > 13) {
+        fail(BFHIP_EINVAL, "Invalid length %d (power of two in 64..8192 required).", length);
+        return nullptr;
+    }
+    if (n_blocks < 1 || n_in < 1 || n_out < 1) { fail(BFHIP_EINVAL, "bad n_blocks/n_in/n_out"); return nullptr; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        fail(BFHIP_ENODEV, "no HIP device available (there is no CPU fallback)");
+        return nullptr;
+    }
+    if (device < 0 || device >= ndev) { fail(BFHIP_ENODEV, "device %d out of range (%d devices)", device, ndev); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { fail(BFHIP_ENODEV, "hipSetDevice(%d) failed", device); return nullptr; }
+
+    bfhip_engine *e = new bfhip_engine();
+    e->device = device; e->L = length; e->N = n_blocks; e->rs = realsize; e->log2L = lg;
+    e->n_ch[0] = n_in; e->n_ch[1] = n_out;
+    for (int io = 0; io < 2; io++) {
+        e->fmt[io].resize(e->n_ch[io]);
+        for (int c = 0; c < e->n_ch[io]; c++) {
+            bfhip_format &f = e->fmt[io][c];
+            f.isfloat = 1; f.swap = 0; f.bytes = f.sbytes = realsize; f.scale = 1.0;
+            f.sample_spacing = 1; f.byte_offset = c * length * realsize;
+        }
+    }
+    bool ok = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) == hipSuccess;
+    e->own_stream = ok;
+    // twiddles exp(-2 pi i m / (2L)), computed in double
+    const size_t ntw = (size_t)2 * length;
+    std::vector<unsigned char> tw(ntw * e->csize());
+    for (size_t m = 0; m < ntw; m++) {
+        const double a = -M_PI * (double)m / (double)length;
+        if (realsize == 4) { ((float *)tw.data())[2 * m] = (float)cos(a); ((float *)tw.data())[2 * m + 1] = (float)sin(a); }
+        else { ((double *)tw.data())[2 * m] = cos(a); ((double *)tw.data())[2 * m + 1] = sin(a); }
+    }
+    ok = ok && hipMalloc(&e->d_tw, tw.size()) == hipSuccess;
+    ok = ok && hipMemcpy(e->d_tw, tw.data(), tw.size(), hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMalloc((void **)&e->d_bad, sizeof(int)) == hipSuccess;
+    ok = ok && hipMemset(e->d_bad, 0, sizeof(int)) == hipSuccess;
+    if (!ok) {
+        fail(BFHIP_EHIP, "device set-up failed: %s", hipGetErrorString(hipGetLastError()));
+        bfhip_engine_destroy(e);
+        return nullptr;
+    }
+    return e;
+}
+
+void bfhip_engine_destroy(bfhip_engine *e) {
+    if (e == nullptr) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (auto &c : e->coeffs) if (c.d_H) (void)hipFree(c.d_H);
+    void *ptrs[] = {e->d_tw, e->d_prev, e->d_ring, e->d_fmt[0], e->d_fmt[1], e->d_over, e->d_status,
+                    e->d_bad, e->d_Zp, e->d_entries, e->d_chunks, e->d_rawin, e->d_rawout, e->d_taps};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (auto ev : e->ev) (void)hipEventDestroy(ev);
+    if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int bfhip_engine_set_format(bfhip_engine *e, int io, int ch, const bfhip_format *bf) {
+    if (!e || !bf || io < 0 || io > 1 || ch < 0 || ch >= e->n_ch[io]) return fail(BFHIP_EINVAL, "set_format: bad argument");
+    if (!check_format(bf)) return fail(BFHIP_EINVAL, "Sample byte size %d is not supported.", bf->bytes);
+    if (e->finalized) return fail(BFHIP_ESTATE, "set_format after finalize");
+    e->fmt[io][ch] = *bf;
+    return BFHIP_OK;
+}
+
+int bfhip_engine_set_safety_limit(bfhip_engine *e, double limit) {
+    if (!e) return fail(BFHIP_EINVAL, "null engine");
+    e->safety_limit = limit;
+    return BFHIP_OK;
+}
+
+int bfhip_engine_enable_dither(bfhip_engine *e, const int[], int, int, int) {
+    (void)e;
+    return fail(BFHIP_EINVAL, "dither is not available in this build of the device path");
+}
+
+static int add_coeff_common(bfhip_engine *e, const void *taps, bool on_device, int n_taps,
+                            double scale, int n_blocks) {
+    if (!e || (!taps && n_taps > 0) || n_taps < 0) return fail(BFHIP_EINVAL, "add_coeff: bad argument");
+    HIPCHK(hipSetDevice(e->device));
+    const int L = e->L;
+    if (n_blocks <= 0) n_blocks = (n_taps + L - 1) / L;
+    if (n_blocks < 1) n_blocks = 1;
+    if (n_blocks > e->N) return fail(BFHIP_EINVAL, "coefficient set needs %d blocks, engine has %d", n_blocks, e->N);
+    if (n_taps > n_blocks * L) n_taps = n_blocks * L;
+    const void *src = taps;
+    if (!on_device && n_taps > 0) {
+        const size_t bytes = (size_t)n_taps * e->rs;
+        if (bytes > e->taps_cap) {
+            if (e->d_taps) { HIPCHK(hipStreamSynchronize(e->stream)); (void)hipFree(e->d_taps); e->d_taps = nullptr; }
+            HIPCHK(hipMalloc(&e->d_taps, bytes));
+            e->taps_cap = bytes;
+        }
+        HIPCHK(hipStreamSynchronize(e->stream));
+        HIPCHK(hipMemcpy(e->d_taps, taps, bytes, hipMemcpyHostToDevice));
+        src = e->d_taps;
+    }
+    Coeff c;
+    c.n_blocks = n_blocks;
+    if (hipMalloc(&c.d_H, (size_t)n_blocks * L * e->csize()) != hipSuccess)
+        return fail(BFHIP_ENOMEM, "out of device memory for coefficient set");
+    hipError_t err = hipSuccess;
+    DISPATCH(launch_coeff_prep, e, src, n_taps, scale, c.d_H, n_blocks, &err);
+    if (err != hipSuccess) { (void)hipFree(c.d_H); return fail(BFHIP_EHIP, "coeff_prep launch: %s", hipGetErrorString(err)); }
+    if (!on_device) {
+        // host-taps path is synchronous, like convolver_coeffs2cbuf: report NaN/Inf now
+        int bad = 0;
+        HIPCHK(hipStreamSynchronize(e->stream));
+        HIPCHK(hipMemcpy(&bad, e->d_bad, sizeof(int), hipMemcpyDeviceToHost));
+        if (bad) {
+            HIPCHK(hipMemset(e->d_bad, 0, sizeof(int)));
+            (void)hipFree(c.d_H);
+            return fail(BFHIP_EINVAL, "NaN or Inf value among coefficients.");
+        }
+    }
+    e->coeffs.push_back(c);
+    return (int)e->coeffs.size() - 1;
+}
+
+int bfhip_engine_add_coeff(bfhip_engine *e, const void *taps, int n_taps, double scale, int n_blocks) {
+    return add_coeff_common(e, taps, false, n_taps, scale, n_blocks);
+}
+
+int bfhip_engine_add_coeff_dev(bfhip_engine *e, const void *taps_dev, int n_taps, double scale, int n_blocks) {
+    return add_coeff_common(e, taps_dev, true, n_taps, scale, n_blocks);
+}
+
+int bfhip_engine_update_coeff_block(bfhip_engine *e, int coeff, int block, const void *taps) {
+    if (!e || coeff < 0 || coeff >= (int)e->coeffs.size() || block < 0 ||
+        block >= e->coeffs[coeff].n_blocks || !taps)
+        return fail(BFHIP_EINVAL, "update_coeff_block: bad argument");
+    HIPCHK(hipSetDevice(e->device));
+    const size_t bytes = (size_t)e->L * e->rs;
+    if (bytes > e->taps_cap) {
+        if (e->d_taps) { HIPCHK(hipStreamSynchronize(e->stream)); (void)hipFree(e->d_taps); e->d_taps = nullptr; }
+        HIPCHK(hipMalloc(&e->d_taps, bytes));
+        e->taps_cap = bytes;
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(e->d_taps, taps, bytes, hipMemcpyHostToDevice));
+    void *H = (unsigned char *)e->coeffs[coeff].d_H + (size_t)block * e->L * e->csize();
+    hipError_t err = hipSuccess;
+    DISPATCH(launch_coeff_prep, e, e->d_taps, e->L, 1.0, H, 1, &err);
+    if (err != hipSuccess) return fail(BFHIP_EHIP, "coeff_prep launch: %s", hipGetErrorString(err));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return BFHIP_OK;
+}
+
+int bfhip_engine_add_filter(bfhip_engine *e,
+                            int n_in_ch, const int in_ch[], const double in_scale[],
+                            int n_in_f, const int in_f[], const double in_fscale[],
+                            int n_out_ch, const int out_ch[], const double out_scale[],
+                            int coeff, int delayblocks, int crossfade) {
+    if (!e) return fail(BFHIP_EINVAL, "null engine");
+    if (e->finalized) return fail(BFHIP_ESTATE, "add_filter after finalize");
+    if (n_in_ch < 0 || n_in_f < 0 || n_out_ch < 0) return fail(BFHIP_EINVAL, "add_filter: negative count");
+    Filter f;
+    for (int i = 0; i < n_in_ch; i++) {
+        if (in_ch[i] < 0 || in_ch[i] >= e->n_ch[0]) return fail(BFHIP_EINVAL, "add_filter: input channel %d", in_ch[i]);
+        f.in_ch.push_back(in_ch[i]); f.in_scale.push_back(in_scale[i]);
+    }
+    for (int i = 0; i < n_in_f; i++) {
+        if (in_f[i] < 0 || in_f[i] >= (int)e->filters.size()) return fail(BFHIP_EINVAL, "add_filter: from_filter %d not defined yet", in_f[i]);
+        f.in_f.push_back(in_f[i]); f.in_fscale.push_back(in_fscale[i]);
+    }
+    for (int i = 0; i < n_out_ch; i++) {
+        if (out_ch[i] < 0 || out_ch[i] >= e->n_ch[1]) return fail(BFHIP_EINVAL, "add_filter: output channel %d", out_ch[i]);
+        f.out_ch.push_back(out_ch[i]); f.out_scale.push_back(out_scale[i]);
+    }
+    if (coeff >= (int)e->coeffs.size()) return fail(BFHIP_EINVAL, "add_filter: coeff %d not loaded", coeff);
+    f.coeff = coeff; f.delayblocks = delayblocks; f.crossfade = crossfade; f.prevcoeff = coeff;
+    e->filters.push_back(f);
+    return (int)e->filters.size() - 1;
+}
+
+int bfhip_engine_finalize(bfhip_engine *e) {
+    if (!e) return fail(BFHIP_EINVAL, "null engine");
+    if (e->finalized) return BFHIP_OK;
+    HIPCHK(hipSetDevice(e->device));
+    const size_t L = e->L;
+    const size_t prev_b = (size_t)e->n_ch[0] * L * e->rs;
+    const size_t ring_b = (size_t)e->n_ch[0] * e->N * L * e->csize();
+    if (hipMalloc(&e->d_prev, prev_b) != hipSuccess || hipMalloc(&e->d_ring, ring_b) != hipSuccess)
+        return fail(BFHIP_ENOMEM, "out of device memory for the spectrum rings");
+    HIPCHK(hipMemset(e->d_prev, 0, prev_b));       // bfrun.c:1388: everything starts zeroed
+    HIPCHK(hipMemset(e->d_ring, 0, ring_b));
+    for (int io = 0; io < 2; io++) HIPCHK(hipMalloc((void **)&e->d_fmt[io], e->n_ch[io] * sizeof(DevFormat)));
+    int r = upload_formats(e);
+    if (r != BFHIP_OK) return r;
+    HIPCHK(hipMalloc((void **)&e->d_over, e->n_ch[1] * sizeof(DevOverflow)));
+    HIPCHK(hipMalloc((void **)&e->d_status, sizeof(int)));
+    HIPCHK(hipMemset(e->d_status, 0, sizeof(int)));
+    e->raw_bytes[0] = raw_extent(e->fmt[0], e->L);
+    e->raw_bytes[1] = raw_extent(e->fmt[1], e->L);
+    HIPCHK(hipMalloc((void **)&e->d_rawin, e->raw_bytes[0]));
+    HIPCHK(hipMalloc((void **)&e->d_rawout, e->raw_bytes[1]));
+    HIPCHK(hipMemset(e->d_rawout, 0, e->raw_bytes[1]));
+    e->finalized = true;
+    r = bfhip_engine_reset_overflow(e);
+    if (r != BFHIP_OK) return r;
+    // coefficient sets loaded from device memory are checked here
+    int bad = 0;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(&bad, e->d_bad, sizeof(int), hipMemcpyDeviceToHost));
+    if (bad) return fail(BFHIP_EINVAL, "NaN or Inf value among coefficients.");
+    return build_plan(e);
+}
+
+int bfhip_engine_set_coeff(bfhip_engine *e, int filter, int coeff) {
+    if (!e || filter < 0 || filter >= (int)e->filters.size() || coeff >= (int)e->coeffs.size())
+        return fail(BFHIP_EINVAL, "set_coeff: bad argument");
+    if (e->filters[filter].coeff != coeff) { e->filters[filter].coeff = coeff; e->plan_dirty = true; }
+    return BFHIP_OK;
+}
+
+int bfhip_engine_set_delayblocks(bfhip_engine *e, int filter, int blocks) {
+    if (!e || filter < 0 || filter >= (int)e->filters.size()) return fail(BFHIP_EINVAL, "set_delayblocks: bad argument");
+    if (e->filters[filter].delayblocks != blocks) { e->filters[filter].delayblocks = blocks; e->plan_dirty = true; }
+    return BFHIP_OK;
+}
+
+int bfhip_engine_set_scale(bfhip_engine *e, int filter, int io, int index, double scale) {
+    if (!e || filter < 0 || filter >= (int)e->filters.size() || io < 0 || io > 1) return fail(BFHIP_EINVAL, "set_scale: bad argument");
+    auto &v = io == 0 ? e->filters[filter].in_scale : e->filters[filter].out_scale;
+    if (index < 0 || index >= (int)v.size()) return fail(BFHIP_EINVAL, "set_scale: bad index");
+    if (v[index] != scale) { v[index] = scale; e->plan_dirty = true; }
+    return BFHIP_OK;
+}
+
+int bfhip_engine_set_fscale(bfhip_engine *e, int filter, int index, double scale) {
+    if (!e || filter < 0 || filter >= (int)e->filters.size()) return fail(BFHIP_EINVAL, "set_fscale: bad argument");
+    auto &v = e->filters[filter].in_fscale;
+    if (index < 0 || index >= (int)v.size()) return fail(BFHIP_EINVAL, "set_fscale: bad index");
+    if (v[index] != scale) { v[index] = scale; e->plan_dirty = true; }
+    return BFHIP_OK;
+}
+
+int bfhip_engine_inputs_dev(bfhip_engine *e, const void *rawin_dev) {
+    int r = ensure_ready(e);
+    if (r != BFHIP_OK) return r;
+    return do_inputs(e, rawin_dev);
+}
+
+int bfhip_engine_mac_dev(bfhip_engine *e, void *z_dev) {
+    int r = ensure_ready(e);
+    if (r != BFHIP_OK) return r;
+    if (e->n_chunks == 1 && e->n_out_padded == e->n_ch[1]) return do_mac(e, z_dev);
+    r = do_mac(e, e->d_Zp);
+    if (r != BFHIP_OK) return r;
+    hipError_t err = hipSuccess;
+    if (e->rs == 4) launch_sum<float>(e, e->d_Zp, z_dev, &err); else launch_sum<double>(e, e->d_Zp, z_dev, &err);
+    if (err != hipSuccess) return fail(BFHIP_EHIP, "sum_partials launch: %s", hipGetErrorString(err));
+    return BFHIP_OK;
+}
+
+int bfhip_engine_outputs_dev(bfhip_engine *e, const void *z_dev, int first, int count, void *rawout_dev) {
+    int r = ensure_ready(e);
+    if (r != BFHIP_OK) return r;
+    if (first < 0 || count < 0 || first + count > e->n_ch[1]) return fail(BFHIP_EINVAL, "outputs: channel range");
+    return do_outputs(e, z_dev, 0, 1, first, count, rawout_dev);
+}
+
+int bfhip_engine_advance(bfhip_engine *e) {
+    if (!e) return fail(BFHIP_EINVAL, "null engine");
+    advance(e);
+    return BFHIP_OK;
+}
+
+int bfhip_engine_block_dev(bfhip_engine *e, const void *rawin_dev, void *rawout_dev) {
+    int r = ensure_ready(e);
+    if (r != BFHIP_OK) return r;
+    if ((r = record(e, 0)) != BFHIP_OK) return r;
+    if ((r = do_inputs(e, rawin_dev)) != BFHIP_OK) return r;
+    if ((r = record(e, 1)) != BFHIP_OK) return r;
+    if ((r = do_mac(e, e->d_Zp)) != BFHIP_OK) return r;
+    if ((r = record(e, 2)) != BFHIP_OK) return r;
+    if ((r = do_outputs(e, e->d_Zp, (size_t)e->n_out_padded * e->L, e->n_chunks, 0, e->n_ch[1], rawout_dev)) != BFHIP_OK) return r;
+    if ((r = record(e, 3)) != BFHIP_OK) return r;
+    if (e->timing && e->ev_used < MAX_TIMED) e->ev_used++;
+    advance(e);
+    return BFHIP_OK;
+}
+
+int bfhip_engine_sync(bfhip_engine *e) {
+    if (!e || !e->finalized) return fail(BFHIP_ESTATE, "engine not finalized");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    int st = 0;
+    HIPCHK(hipMemcpy(&st, e->d_status, sizeof(int), hipMemcpyDeviceToHost));
+    if (st) HIPCHK(hipMemset(e->d_status, 0, sizeof(int)));
+    return st;
+}
+
+int bfhip_engine_block(bfhip_engine *e, const void *rawin, void *rawout, bfhip_overflow overflow[]) {
+    int r = ensure_ready(e);
+    if (r != BFHIP_OK) return r;
+    if (!rawin || !rawout) return fail(BFHIP_EINVAL, "block: null buffer");
+    static_assert(sizeof(bfhip_overflow) == sizeof(DevOverflow), "overflow struct layout");
+    if (overflow) HIPCHK(hipMemcpyAsync(e->d_over, overflow, e->n_ch[1] * sizeof(DevOverflow), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d_rawin, rawin, e->raw_bytes[0], hipMemcpyHostToDevice, e->stream));
+    if ((r = bfhip_engine_block_dev(e, e->d_rawin, e->d_rawout)) != BFHIP_OK) return r;
+    HIPCHK(hipMemcpyAsync(rawout, e->d_rawout, e->raw_bytes[1], hipMemcpyDeviceToHost, e->stream));
+    if (overflow) HIPCHK(hipMemcpyAsync(overflow, e->d_over, e->n_ch[1] * sizeof(DevOverflow), hipMemcpyDeviceToHost, e->stream));
+    return bfhip_engine_sync(e);
+}
+
+int bfhip_engine_set_stream(bfhip_engine *e, void *hip_stream) {
+    if (!e) return fail(BFHIP_EINVAL, "null engine");
+    HIPCHK(hipSetDevice(e->device));
+    if (e->stream) HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+    e->stream = (hipStream_t)hip_stream;
+    e->own_stream = false;
+    return BFHIP_OK;
+}
+
+int bfhip_engine_get_overflow(bfhip_engine *e, int ch, bfhip_overflow *of) {
+    if (!e || !e->finalized || ch < 0 || ch >= e->n_ch[1] || !of) return fail(BFHIP_EINVAL, "get_overflow: bad argument");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(of, e->d_over + ch, sizeof(DevOverflow), hipMemcpyDeviceToHost));
+    return BFHIP_OK;
+}
+
+int bfhip_engine_reset_overflow(bfhip_engine *e) {
+    if (!e || !e->finalized) return fail(BFHIP_ESTATE, "engine not finalized");
+    HIPCHK(hipSetDevice(e->device));
+    std::vector<DevOverflow> v(e->n_ch[1]);
+    for (int c = 0; c < e->n_ch[1]; c++) {
+        memset(&v[c], 0, sizeof(DevOverflow));
+        v[c].max = overflow_max(e->fmt[1][c]);
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(e->d_over, v.data(), v.size() * sizeof(DevOverflow), hipMemcpyHostToDevice));
+    return BFHIP_OK;
+}
+
+unsigned int bfhip_engine_blockcounter(const bfhip_engine *e) { return e ? e->blockcounter : 0; }
+
+int bfhip_engine_enable_timing(bfhip_engine *e, int on) {
+    if (!e) return fail(BFHIP_EINVAL, "null engine");
+    HIPCHK(hipSetDevice(e->device));
+    if (on && e->ev.empty()) {
+        e->ev.resize((size_t)MAX_TIMED * 4);
+        for (auto &x : e->ev) HIPCHK(hipEventCreate(&x));
+    }
+    if (e->stream) HIPCHK(hipStreamSynchronize(e->stream));
+    e->timing = on != 0;
+    e->ev_used = 0;
+    return BFHIP_OK;
+}
+
+int bfhip_engine_get_timing(bfhip_engine *e, double ms[4]) {
+    if (!e || !ms) return fail(BFHIP_EINVAL, "get_timing: bad argument");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    ms[0] = ms[1] = ms[2] = 0; ms[3] = e->ev_used;
+    for (int i = 0; i < e->ev_used; i++) {
+        for (int k = 0; k < 3; k++) {
+            float t = 0;
+            HIPCHK(hipEventElapsedTime(&t, e->ev[(size_t)i * 4 + k], e->ev[(size_t)i * 4 + k + 1]));
+            ms[k] += t;
+        }
+    }
+    if (e->ev_used > 0) for (int k = 0; k < 3; k++) ms[k] /= e->ev_used;
+    e->ev_used = 0;
+    return BFHIP_OK;
+}
+
+int bfhip_engine_algorithmic_bytes(bfhip_engine *e, double bytes[2]) {
+    int r = ensure_ready(e);
+    if (r != BFHIP_OK) return r;
+    bytes[0] = e->alg_bytes_total;
+    bytes[1] = e->alg_bytes_mac;
+    return BFHIP_OK;
+}
+
+int bfhip_engine_read_output_spectrum(bfhip_engine *e, int ch, void *dst) {
+    if (!e || !e->finalized || ch < 0 || ch >= e->n_ch[1] || !dst) return fail(BFHIP_EINVAL, "read_output_spectrum: bad argument");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const size_t row = (size_t)e->L * e->csize();
+    std::vector<unsigned char> tmp(row);
+    memset(dst, 0, row);
+    for (int c = 0; c < e->n_chunks; c++) {
+        HIPCHK(hipMemcpy(tmp.data(), (unsigned char *)e->d_Zp + ((size_t)c * e->n_out_padded + ch) * row, row, hipMemcpyDeviceToHost));
+        const size_t n = (size_t)2 * e->L;
+        if (e->rs == 4) for (size_t i = 0; i < n; i++) ((float *)dst)[i] += ((float *)tmp.data())[i];
+        else for (size_t i = 0; i < n; i++) ((double *)dst)[i] += ((double *)tmp.data())[i];
+    }
+    return BFHIP_OK;
+}
+
+int bfhip_engine_read_ring_slot(bfhip_engine *e, int ch, int slot, void *dst) {
+    if (!e || !e->finalized || ch < 0 || ch >= e->n_ch[0] || slot < 0 || slot >= e->N || !dst) return fail(BFHIP_EINVAL, "read_ring_slot: bad argument");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const size_t row = (size_t)e->L * e->csize();
+    HIPCHK(hipMemcpy(dst, (unsigned char *)e->d_ring + ((size_t)ch * e->N + slot) * row, row, hipMemcpyDeviceToHost));
+    return BFHIP_OK;
+}
+
+}  // extern "C"

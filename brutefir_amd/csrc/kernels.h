@@ -1,0 +1,469 @@
+// kernels.h -- the device side of the filter path (gfx950 only).
+//
+// Spectrum layout in HBM ("packed spectrum"): L complex numbers per 2L-point real
+// transform; element k (1 <= k < L) is bin X[k]; element 0 carries the two purely real
+// bins as (Re X[0], Re X[L]).  This is the device-internal counterpart of the reference's
+// "4 re / 4 im" cbuf layout (fftw_convfuns.h:25-43) -- same information, bins contiguous
+// so that one lane's 16-byte access is two whole bins and a wave reads 1 KiB contiguous.
+//
+//   K1 fft_in_kernel     raw2cbuf + time2freq     fftw_convolver.c:170-214, raw2real.h
+//   K2 mac_xbar_kernel   mixnscale(INPUT) + convolve + convolve_add* + dirac +
+//                        mixnscale(OUTPUT)        fftw_convfuns.h:7-619, bfrun.c:1566-1868
+//   K3 ifft_out_kernel   freq2time + cbuf2raw     fftw_convolver.c:391-409, 482-518,
+//                                                 real2raw.h, dither_funs.h:71-114
+//   K7 coeff_prep_kernel coeffs2cbuf              fftw_convolver.c:526-573
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fft_lds.h"
+
+namespace bfhip {
+
+// ------------------------------------------------------------------ shared structs
+
+struct DevFormat {          // bfhip_format, device copy
+    int isfloat, swap, bytes, sbytes;
+    int sample_spacing, byte_offset;
+};
+
+struct DevOverflow {        // struct bfoverflow (bfmod.h:99-104)
+    unsigned int n_overflows;
+    int32_t intlargest;
+    double largest;
+    double max;
+};
+
+constexpr int OG = 8;       // outputs accumulated per MAC workgroup
+
+enum { TERM_NONE = -1, TERM_COEFF = 0, TERM_DIRAC = 1, TERM_IDENT = 2 };
+
+template <typename T> struct MacTerm {
+    const c2<T> *H;     // coefficient set: [n_blocks][L] packed spectra (already / n_fft)
+    T scale;            // input scale * sf.scale * output scale / sf_out.scale
+    int P;              // partitions to accumulate (cblocks, bfrun.c:1585-1591)
+    int kind;           // TERM_*
+};
+
+template <typename T> struct MacEntry {
+    const c2<T> *ring;  // [R][L] packed spectra of past blocks
+    int R;              // ring depth
+    int delay;          // filter delay in blocks (bfrun.c:1579-1584)
+    int maxP;           // max over terms of P
+    int pad;
+    MacTerm<T> term[OG];
+};
+
+struct ChunkRange { int begin, end; };
+
+// ------------------------------------------------------------------ raw sample access
+
+template <typename T>
+__device__ __forceinline__ T load_raw(const uint8_t *p, const DevFormat &f) {
+    uint8_t t[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) t[i] = 0;
+    if (f.swap && f.bytes != 3) {
+        for (int i = 0; i < f.bytes; i++) t[i] = p[f.bytes - 1 - i];
+    } else {
+        for (int i = 0; i < f.bytes; i++) t[i] = p[i];
+    }
+    const uint32_t lo = (uint32_t)t[0] | (uint32_t)t[1] << 8 | (uint32_t)t[2] << 16 | (uint32_t)t[3] << 24;
+    if (f.isfloat) {
+        if (f.bytes == 4) return (T)__uint_as_float(lo);
+        const uint32_t hi = (uint32_t)t[4] | (uint32_t)t[5] << 8 | (uint32_t)t[6] << 16 | (uint32_t)t[7] << 24;
+        return (T)__longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+    }
+    switch (f.bytes) {
+    case 1: return (T)(int8_t)t[0];
+    case 2: return (T)(int16_t)(lo & 0xffff);
+    case 3: {
+        // packed 24 bit: into the top of an int32, arithmetic shift down (raw2real.h:106-142)
+        const uint32_t u = f.swap ? ((uint32_t)t[2] << 8 | (uint32_t)t[1] << 16 | (uint32_t)t[0] << 24)
+                                  : ((uint32_t)t[0] << 8 | (uint32_t)t[1] << 16 | (uint32_t)t[2] << 24);
+        return (T)((int32_t)u >> 8);
+    }
+    default: return (T)(int32_t)lo;
+    }
+}
+
+__device__ __forceinline__ void store_raw_bytes(uint8_t *p, const uint8_t *t, int bytes, int swap) {
+    if (swap) {
+        for (int i = 0; i < bytes; i++) p[i] = t[bytes - 1 - i];
+    } else {
+        for (int i = 0; i < bytes; i++) p[i] = t[i];
+    }
+}
+
+// ------------------------------------------------------------------ K1: raw -> spectrum
+
+// One workgroup per input channel.  Window = [previous L samples | new L samples]
+// (fftw_convolver.c:181-193); z[n] = x[2n] + i x[2n+1]; complex FFT; untangle; write the
+// packed spectrum into ring slot `slot` of that channel.
+template <typename T, int LOG2L>
+__global__ __launch_bounds__(fft_threads(LOG2L)) void
+fft_in_kernel(const uint8_t *__restrict__ raw, const DevFormat *__restrict__ fmt,
+              T *__restrict__ prev,            // [n_in][L] last block's samples
+              c2<T> *__restrict__ ring,        // [n_in][R][L]
+              const c2<T> *__restrict__ tw, int R, int slot) {
+    constexpr int L = 1 << LOG2L, NT = fft_threads(LOG2L);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    c2<T> *s = reinterpret_cast<c2<T> *>(smem);
+    const int ch = blockIdx.x, tid = threadIdx.x;
+    const DevFormat f = fmt[ch];
+    T *pv = prev + (size_t)ch * L;
+    const uint8_t *base = raw + f.byte_offset;
+    const size_t stride = (size_t)f.sample_spacing * f.bytes;
+
+    // first half of z from the previous block, second half from the new samples
+    for (int n = tid; n < L / 2; n += NT) {
+        s[n] = mk<T>(pv[2 * n], pv[2 * n + 1]);
+    }
+    __syncthreads();   // all reads of prev done before it is overwritten
+    for (int n = tid; n < L / 2; n += NT) {
+        const T a = load_raw<T>(base + (size_t)(2 * n) * stride, f);
+        const T b = load_raw<T>(base + (size_t)(2 * n + 1) * stride, f);
+        s[L / 2 + n] = mk<T>(a, b);
+        pv[2 * n] = a;
+        pv[2 * n + 1] = b;
+    }
+    __syncthreads();
+    lds_fft<T, LOG2L, NT, false>(s, tw);
+
+    // X[k] = E[k] + w^k O[k], X[L-k] = conj(E[k] - w^k O[k]),  w = exp(-i pi / L)
+    c2<T> *out = ring + ((size_t)ch * R + slot) * L;
+    for (int k = tid; k <= L / 2; k += NT) {
+        if (k == 0) {
+            out[0] = mk<T>(s[0].x + s[0].y, s[0].x - s[0].y);
+        } else {
+            const c2<T> a = s[k], b = conj(s[L - k]);
+            const c2<T> e = mk<T>((T)0.5 * (a.x + b.x), (T)0.5 * (a.y + b.y));
+            const c2<T> d = mk<T>((T)0.5 * (a.x - b.x), (T)0.5 * (a.y - b.y));
+            const c2<T> o = mk<T>(d.y, -d.x);           // d / i
+            const c2<T> wo = cmul(o, tw[k]);
+            out[k] = e + wo;
+            if (k != L - k) out[L - k] = conj(e - wo);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ K7: taps -> coefficient partition
+
+// One workgroup per partition: [0..L) zero, [L..2L) = taps * scale, real FFT, * 1/n_fft.
+// (fftw_convolver.c:535-569).  bad[0] is set if a scaled tap is not finite.
+template <typename T, int LOG2L>
+__global__ __launch_bounds__(fft_threads(LOG2L)) void
+coeff_prep_kernel(const T *__restrict__ taps, int n_taps, T scale, c2<T> *__restrict__ H,
+                  const c2<T> *__restrict__ tw, int *__restrict__ bad) {
+    constexpr int L = 1 << LOG2L, NT = fft_threads(LOG2L);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    c2<T> *s = reinterpret_cast<c2<T> *>(smem);
+    const int part = blockIdx.x, tid = threadIdx.x;
+    const int first = part * L;
+    int notfinite = 0;
+    for (int n = tid; n < L / 2; n += NT) {
+        s[n] = mk<T>((T)0, (T)0);
+        const int i0 = first + 2 * n, i1 = i0 + 1;
+        const T a = i0 < n_taps ? taps[i0] * scale : (T)0;
+        const T b = i1 < n_taps ? taps[i1] * scale : (T)0;
+        if (!isfinite(a) || !isfinite(b)) notfinite = 1;
+        s[L / 2 + n] = mk<T>(a, b);
+    }
+    if (notfinite) atomicOr(bad, 1);
+    __syncthreads();
+    lds_fft<T, LOG2L, NT, false>(s, tw);
+    const T inv = (T)1.0 / (T)(2 * L);
+    c2<T> *out = H + (size_t)part * L;
+    for (int k = tid; k <= L / 2; k += NT) {
+        if (k == 0) {
+            out[0] = mk<T>((s[0].x + s[0].y) * inv, (s[0].x - s[0].y) * inv);
+        } else {
+            const c2<T> a = s[k], b = conj(s[L - k]);
+            const c2<T> e = mk<T>((T)0.5 * (a.x + b.x), (T)0.5 * (a.y + b.y));
+            const c2<T> d = mk<T>((T)0.5 * (a.x - b.x), (T)0.5 * (a.y - b.y));
+            const c2<T> o = mk<T>(d.y, -d.x);
+            const c2<T> wo = cmul(o, tw[k]);
+            const c2<T> x = e + wo, y = conj(e - wo);
+            out[k] = mk<T>(x.x * inv, x.y * inv);
+            if (k != L - k) out[L - k] = mk<T>(y.x * inv, y.y * inv);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ K2: crossbar MAC
+
+// Z[o][k] (+)= sum over entries (ring, delay) and partitions p of
+//              scale * ring[(t - p - delay) mod R][k] * H[p][k]
+// Work decomposition: workgroup = (bin tile, output group of OG, chunk of the group's
+// entries).  A lane owns V consecutive bins (16 bytes); the ring value is loaded once per
+// (entry, p) and reused in registers for the OG outputs; each coefficient element is read
+// exactly once per block, as a 1 KiB-per-wave contiguous load.  The 8 output groups that
+// need the same ring tile get the same blockIdx%8 (one XCD, adjacent dispatch) so that the
+// ring re-reads hit that XCD's L2.  Partial sums of the chunks go to Zp[chunk][o][k] and
+// are added up by the consumer (K3 or sum_partials_kernel): deterministic, no atomics.
+template <typename T>
+__global__ __launch_bounds__(256) void
+mac_xbar_kernel(const MacEntry<T> *__restrict__ entries, const ChunkRange *__restrict__ chunks,
+                c2<T> *__restrict__ Zp, int L, int n_out_padded, int n_groups, int n_chunks,
+                int n_tc, unsigned int t, int age) {
+    constexpr int V = 16 / sizeof(c2<T>);          // bins per lane: 2 (f32) / 1 (f64)
+    // XCD-aware decode (blocks b and b+8 share an XCD)
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, local = bid >> 3;
+    const int group = local % n_groups;
+    const int tc = (local / n_groups) * 8 + xcd;
+    if (tc >= n_tc) return;
+    const int tile = tc / n_chunks, chunk = tc % n_chunks;
+    const int k0 = (tile * (int)blockDim.x + (int)threadIdx.x) * V;
+    if (k0 >= L) return;
+    const bool dc = (k0 == 0);
+    const T am = dc ? (T)0 : (T)1;
+
+    T acc[OG][2 * V];
+#pragma unroll
+    for (int j = 0; j < OG; j++)
+#pragma unroll
+        for (int v = 0; v < 2 * V; v++) acc[j][v] = (T)0;
+
+    const ChunkRange cr = chunks[group * n_chunks + chunk];
+    for (int e = cr.begin; e < cr.end; e++) {
+        const MacEntry<T> *E = &entries[e];
+        const c2<T> *ring = E->ring;
+        const int R = E->R, delay = E->delay;
+        int maxP = E->maxP;
+        if (maxP > age - delay) maxP = age - delay;     // blocks that exist yet (procblocks)
+        for (int p = 0; p < maxP; p++) {
+            const unsigned int slot = (t - (unsigned int)p - (unsigned int)delay) % (unsigned int)R;
+            c2<T> x[V];
+            {
+                const c2<T> *xp = ring + (size_t)slot * L + k0;
+                if constexpr (V == 2) {
+                    const float4 q = *reinterpret_cast<const float4 *>(xp);
+                    x[0] = mk<T>(q.x, q.y); x[1] = mk<T>(q.z, q.w);
+                } else {
+                    x[0] = *xp;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < OG; j++) {
+                const int kind = E->term[j].kind;
+                if (kind == TERM_NONE || p >= E->term[j].P) continue;
+                const T sc = E->term[j].scale;
+                c2<T> h[V];
+                if (kind == TERM_COEFF) {
+                    const c2<T> *hp = E->term[j].H + (size_t)p * L + k0;
+                    if constexpr (V == 2) {
+                        const float4 q = *reinterpret_cast<const float4 *>(hp);
+                        h[0] = mk<T>(q.x, q.y); h[1] = mk<T>(q.z, q.w);
+                    } else {
+                        h[0] = *hp;
+                    }
+                } else if (kind == TERM_DIRAC) {
+                    // spectrum of a unit pulse at sample L over n_fft: (-1)^k / n_fft
+                    // (fftw_convfuns.h:592-619); bins k0 (even) and k0+1 (odd)
+                    const T f = (T)1.0 / (T)(2 * L);
+                    if constexpr (V == 2) { h[0] = mk<T>(f, (T)0); h[1] = mk<T>(-f, (T)0); }
+                    else { h[0] = mk<T>((k0 & 1) ? -f : f, (T)0); }
+                    if (dc) h[0] = mk<T>(f, f);
+                } else {
+                    h[0] = mk<T>((T)1, (T)0);
+                    if constexpr (V == 2) h[1] = mk<T>((T)1, (T)0);
+                    if (dc) h[0] = mk<T>((T)1, (T)1);
+                }
+                // first bin of the lane: element 0 of the spectrum is (DC, Nyquist), a
+                // real*real product per component (fftw_convfuns.h:545-559)
+                {
+                    const T xr = x[0].x * sc, xi = x[0].y * sc;
+                    const T hsel = dc ? h[0].y : h[0].x;
+                    acc[j][0] += xr * h[0].x - (am * xi) * h[0].y;
+                    acc[j][1] += (am * xr) * h[0].y + xi * hsel;
+                }
+                if constexpr (V == 2) {
+                    const T xr = x[1].x * sc, xi = x[1].y * sc;
+                    acc[j][2] += xr * h[1].x - xi * h[1].y;
+                    acc[j][3] += xr * h[1].y + xi * h[1].x;
+                }
+            }
+        }
+    }
+    c2<T> *zp = Zp + ((size_t)chunk * n_out_padded + (size_t)group * OG) * L + k0;
+#pragma unroll
+    for (int j = 0; j < OG; j++) {
+        if constexpr (V == 2) {
+            *reinterpret_cast<float4 *>(zp + (size_t)j * L) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+        } else {
+            zp[(size_t)j * L] = mk<T>(acc[j][0], acc[j][1]);
+        }
+    }
+}
+
+// Z[o][k] = sum_c Zp[c][o][k]   (only used when the spectra leave the engine: multi-GPU)
+template <typename T>
+__global__ __launch_bounds__(256) void
+sum_partials_kernel(const c2<T> *__restrict__ Zp, c2<T> *__restrict__ Z, size_t n_per_chunk,
+                    size_t n_valid, int n_chunks) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_valid) return;
+    c2<T> a = Zp[i];
+    for (int c = 1; c < n_chunks; c++) a = a + Zp[(size_t)c * n_per_chunk + i];
+    Z[i] = a;
+}
+
+// ------------------------------------------------------------------ K3: spectrum -> raw
+
+// the no-dither requantiser, literally (dither_funs.h:71-114); both precisions go through
+// the double version in the reference (fftw_convolver.c:448, :471)
+__device__ __forceinline__ int32_t
+real2int_no_dither(double v, double rmin, double rmax, int32_t imin, int32_t imax,
+                   unsigned int &n_over, int32_t &intlargest, double &largest) {
+    int32_t s;
+    v += 0.5;
+    if (v < 0) {
+        if (v <= rmin) {
+            s = imin; n_over++;
+            if (v < -largest) largest = -v;
+        } else {
+            s = (int32_t)v; s--;
+            if (s < -intlargest) intlargest = -s;
+        }
+    } else {
+        if (v > rmax) {
+            s = imax; n_over++;
+            if (v > largest) largest = v;
+        } else {
+            s = (int32_t)v;
+            if (s > intlargest) intlargest = s;
+        }
+    }
+    return s;
+}
+
+// One workgroup per output channel: sum the chunk partials, build Z' = E + iO, inverse
+// complex FFT; samples x[2n], x[2n+1] = Re, Im z[n]; the first L samples are the block's
+// output (fftw_convolver.c:493-515).  Then cbuf2raw: finite / safety tests, quantise or
+// float store, peak + overflow accounting, strided interleaved write.
+// `timeout` (may be NULL): if given, the samples are ALSO stored there as T [count][L]
+// (used by the dither pass and by debug taps).
+template <typename T, int LOG2L>
+__global__ __launch_bounds__(fft_threads(LOG2L)) void
+ifft_out_kernel(const c2<T> *__restrict__ Zp, size_t chunk_stride, int n_chunks,
+                int first_channel, const DevFormat *__restrict__ fmt,
+                DevOverflow *__restrict__ over, const unsigned char *__restrict__ skip_quant,
+                uint8_t *__restrict__ raw, T *__restrict__ timeout,
+                const c2<T> *__restrict__ tw, double safety_limit, int *__restrict__ status) {
+    constexpr int L = 1 << LOG2L, NT = fft_threads(LOG2L);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    c2<T> *s = reinterpret_cast<c2<T> *>(smem);
+    __shared__ unsigned int red_n[16];
+    __shared__ int32_t red_i[16];
+    __shared__ double red_l[16];
+    const int tid = threadIdx.x;
+    const int zi = blockIdx.x;                 // index into Zp's channel axis
+    const int ch = first_channel + zi;         // output channel
+    const c2<T> *z = Zp + (size_t)zi * L;
+
+    for (int k = tid; k <= L / 2; k += NT) {
+        c2<T> a = z[k];
+        for (int c = 1; c < n_chunks; c++) a = a + z[(size_t)c * chunk_stride + k];
+        if (k == 0) {
+            s[0] = mk<T>(a.x + a.y, a.x - a.y);
+        } else {
+            c2<T> b = z[L - k];
+            for (int c = 1; c < n_chunks; c++) b = b + z[(size_t)c * chunk_stride + L - k];
+            b = conj(b);
+            const c2<T> e = a + b, d = a - b;
+            const c2<T> o = cmul(d, conj(tw[k]));               // 2 O[k]
+            s[k] = mk<T>(e.x - o.y, e.y + o.x);                 // 2E + i 2O
+            if (k != L - k) s[L - k] = mk<T>(e.x + o.y, -e.y + o.x);   // conj(2E) + i conj(2O)
+        }
+    }
+    __syncthreads();
+    lds_fft<T, LOG2L, NT, true>(s, tw);
+
+    const DevFormat f = fmt[ch];
+    DevOverflow of = over[ch];
+    uint8_t *base = raw + f.byte_offset;
+    const size_t stride = (size_t)f.sample_spacing * f.bytes;
+    const int bits = f.sbytes << 3;
+    const int32_t imin = (int32_t)(-((uint64_t)1 << (bits - 1)));
+    const int32_t imax = (int32_t)(((uint64_t)1 << (bits - 1)) - 1);
+    const double rmin_i = (double)(T)imin, rmax_i = (double)(T)imax;
+    const T rmin_f = (T)(-of.max), rmax_f = (T)of.max;
+    const bool quant = skip_quant == nullptr || !skip_quant[ch];
+    unsigned int n_over = 0;
+    int32_t intlargest = of.intlargest;
+    double largest = of.largest;
+    int st = 0;
+
+    for (int n = tid; n < L / 2; n += NT) {
+        const c2<T> zz = s[n];
+        T xs[2] = {zz.x, zz.y};
+        if (timeout != nullptr) {
+            timeout[(size_t)zi * L + 2 * n] = xs[0];
+            timeout[(size_t)zi * L + 2 * n + 1] = xs[1];
+        }
+        if (!quant) continue;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const T x = xs[q];
+            uint8_t *p = base + (size_t)(2 * n + q) * stride;
+            uint8_t tb[8];
+            if (!isfinite(x)) { st |= 1; continue; }
+            if (safety_limit != 0.0 && ((double)x < -safety_limit * of.max || (double)x > safety_limit * of.max)) {
+                st |= 2; continue;
+            }
+            if (f.isfloat) {
+                if (x < (T)0) {
+                    if (x < rmin_f) n_over++;
+                    if ((double)x < -largest) largest = -(double)x;
+                } else {
+                    if (x > rmax_f) n_over++;
+                    if ((double)x > largest) largest = (double)x;
+                }
+                if (f.bytes == 4) {
+                    const uint32_t u = __float_as_uint((float)x);
+                    tb[0] = u & 0xff; tb[1] = (u >> 8) & 0xff; tb[2] = (u >> 16) & 0xff; tb[3] = u >> 24;
+                } else {
+                    const uint64_t u = (uint64_t)__double_as_longlong((double)x);
+#pragma unroll
+                    for (int i = 0; i < 8; i++) tb[i] = (u >> (8 * i)) & 0xff;
+                }
+            } else {
+                const int32_t v = real2int_no_dither((double)x, rmin_i, rmax_i, imin, imax,
+                                                     n_over, intlargest, largest);
+                const uint32_t u = (uint32_t)v;
+                tb[0] = u & 0xff; tb[1] = (u >> 8) & 0xff; tb[2] = (u >> 16) & 0xff; tb[3] = u >> 24;
+            }
+            store_raw_bytes(p, tb, f.bytes, f.swap);
+        }
+    }
+
+    // workgroup reduction of the overflow bookkeeping (order independent: count, max, max)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        n_over += __shfl_down(n_over, off);
+        const int32_t oi = __shfl_down(intlargest, off);
+        intlargest = oi > intlargest ? oi : intlargest;
+        const double ol = __shfl_down(largest, off);
+        largest = ol > largest ? ol : largest;
+        st |= __shfl_down(st, off);
+    }
+    const int wave = tid >> 6, lane = tid & 63;
+    __shared__ int red_s[16];
+    if (lane == 0) { red_n[wave] = n_over; red_i[wave] = intlargest; red_l[wave] = largest; red_s[wave] = st; }
+    __syncthreads();
+    if (tid == 0 && quant) {
+        for (int w = 1; w < NT / 64; w++) {
+            n_over += red_n[w];
+            intlargest = red_i[w] > intlargest ? red_i[w] : intlargest;
+            largest = red_l[w] > largest ? red_l[w] : largest;
+            st |= red_s[w];
+        }
+        over[ch].n_overflows = of.n_overflows + n_over;
+        over[ch].intlargest = intlargest;
+        over[ch].largest = largest;
+        if (st) atomicOr(status, st);
+    }
+}
+
+}  // namespace bfhip

@@ -1,0 +1,182 @@
+/*
+ * bfhip.h -- C ABI of the MI355X-native partitioned-FFT convolution engine that replaces
+ * BruteFIR's filter path (convolver.h + the per-block body of filter_process()).
+ *
+ * Plain C: pointers, ints, doubles.  No HIP, torch or C++ types cross this boundary.
+ * Citations are file:line in the reference tree (chipfunk/brutefir, v1.0o).
+ *
+ * Two levels are exported by libbfhip.so:
+ *
+ *  (1) this file: the FUSED BLOCK API.  One call = everything the reference does between
+ *      `timestamp(&t3)` and `t[7] += t4 - t3` of one filter_process() iteration
+ *      (bfrun.c:1493-2008): raw -> real, forward FFT, input mix, per-filter partitioned
+ *      multiply-accumulate over the ring of past spectra, output mix, inverse FFT,
+ *      real -> raw with overflow accounting.  All state (rings, coefficient partitions,
+ *      overflow structs) lives in HBM.  The patched filter_process() keeps its pipes,
+ *      mutex snapshot and barriers and calls bfhip_engine_block().
+ *
+ *  (2) bfhip_convolver.h: the 22 link-time symbols of convolver.h with the reference's
+ *      host-memory semantics, executed on the device, for everything that is called
+ *      outside the per-block loop (bfconf.c, delay.c, bflogic_eq).
+ *
+ * Error convention follows the host: functions return 0 / a non-negative index
+ * on success and a negative BFHIP_E* code on failure; bfhip_last_error() gives the text.
+ * Nothing here calls exit(); the patched caller decides (bf_exit(BF_EXIT_OTHER)).
+ * If no HIP device / code object is usable every entry point fails with BFHIP_ENODEV:
+ * there is no CPU fallback.
+ */
+#ifndef BFHIP_H
+#define BFHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BFHIP_OK        0
+#define BFHIP_EINVAL   -1   /* bad argument / unsupported configuration */
+#define BFHIP_ENODEV   -2   /* no usable HIP device */
+#define BFHIP_ENOMEM   -3   /* device allocation failed */
+#define BFHIP_EHIP     -4   /* a HIP call or kernel failed */
+#define BFHIP_ESTATE   -5   /* call not valid in this state (e.g. before finalize) */
+
+/* per-block status bits (bfhip_engine_block / bfhip_engine_sync return them, >= 0) */
+#define BFHIP_ST_NONFINITE 1  /* NaN/Inf reached an output: reference abort()s,
+                                 real2raw.h:24-31 and bfrun.c:1903-1911 */
+#define BFHIP_ST_SAFETY    2  /* safety_limit exceeded: reference bf_exit()s, real2raw.h:32-41 */
+
+#define BFHIP_IN  0           /* BF_IN,  bfmod.h:30 */
+#define BFHIP_OUT 1           /* BF_OUT, bfmod.h:31 */
+
+/* struct bfoverflow, bfmod.h:99-104 -- identical field order and types, so the patched
+   host can pass &icomm->overflow[ch] straight through */
+typedef struct bfhip_overflow {
+    unsigned int n_overflows;
+    int32_t intlargest;
+    double largest;
+    double max;
+} bfhip_overflow;
+
+/* struct sample_format (dai.h:21-28, minus the unused `format` tag) followed by the two
+   struct buffer_format fields (dai.h:30-34) */
+typedef struct bfhip_format {
+    int isfloat;
+    int swap;
+    int bytes;            /* bytes per sample in the raw buffer                   */
+    int sbytes;           /* significant bytes (S24_4LE: bytes 4, sbytes 3)       */
+    double scale;         /* sf.scale: 1/2^(8*sbytes-1) for ints, 1.0 for floats  */
+    int sample_spacing;   /* in samples                                           */
+    int byte_offset;      /* of the channel's first sample in the raw buffer      */
+} bfhip_format;
+
+typedef struct bfhip_engine bfhip_engine;
+
+/* library / device */
+int bfhip_device_count(void);
+const char *bfhip_last_error(void);
+const char *bfhip_version(void);
+
+/* ---- construction: what bfconf_init() + the set-up part of filter_process() do ------ */
+
+/* convolver_init(wisdom, length, realsize) (fftw_convolver.c:784-851) + the buffer set-up of
+   filter_process() (bfrun.c:1227-1304, all zeroed as at :1388).  length = partition size L
+   (power of two, 64..8192), n_blocks = N partitions per filter, realsize 4 or 8.
+   n_raw_in/out: size in bytes of one raw input / output buffer (dai_buffer_format->n_bytes).
+   Device initialisation happens here, lazily on first use of the process: call it in the
+   forked filter process, never in the parent. */
+bfhip_engine *bfhip_engine_create(int device, int length, int n_blocks, int realsize,
+                                  int n_in, int n_out);
+void bfhip_engine_destroy(bfhip_engine *e);
+
+/* dai_buffer_format[io]->bf[channel] (dai.c:537-576); 1:1 virtual:physical channels */
+int bfhip_engine_set_format(bfhip_engine *e, int io, int channel, const bfhip_format *bf);
+/* bfconf->safety_limit (linear, 0 = off), bfconf.c "safety_limit" setting */
+int bfhip_engine_set_safety_limit(bfhip_engine *e, double limit);
+/* outputs to dither + dither_init() parameters (dither.c:75-139, bfconf.c:3170-3230) */
+int bfhip_engine_enable_dither(bfhip_engine *e, const int out_channels[], int n,
+                               int sample_rate, int max_size);
+
+/* load_coeff() for a time-domain coefficient set (bfconf.c:1867-2030): split into
+   n_blocks partitions of L taps (n_blocks <= 0: as many as the taps need), each through
+   convolver_coeffs2cbuf (fftw_convolver.c:526-573).  taps are `realsize`-wide reals in
+   host (or, _dev, device) memory.  Returns the coefficient index (>= 0). */
+int bfhip_engine_add_coeff(bfhip_engine *e, const void *taps, int n_taps, double scale,
+                           int n_blocks);
+int bfhip_engine_add_coeff_dev(bfhip_engine *e, const void *taps_dev, int n_taps,
+                               double scale, int n_blocks);
+/* run-time replacement of one partition = convolver_runtime_coeffs2cbuf
+   (fftw_convolver.c:575-596) as used by bflogic_eq (rendereq.h:87-91): L reals */
+int bfhip_engine_update_coeff_block(bfhip_engine *e, int coeff, int block, const void *taps);
+
+/* struct bffilter (bfmod.h:113-121) + its initial struct bffilter_control
+   (bfmod.h:128-133, bfconf->initfctrl).  from_filters must already have been added
+   (the order bfconf.c:2933-2964 establishes).  Returns the filter index. */
+int bfhip_engine_add_filter(bfhip_engine *e,
+                            int n_in_ch, const int in_ch[], const double in_scale[],
+                            int n_in_f, const int in_f[], const double in_fscale[],
+                            int n_out_ch, const int out_ch[], const double out_scale[],
+                            int coeff, int delayblocks, int crossfade);
+
+/* build the device plan; no add_* after this */
+int bfhip_engine_finalize(bfhip_engine *e);
+
+/* ---- run-time control: the fctrl snapshot of bfrun.c:1460-1484 ----------------------- */
+int bfhip_engine_set_coeff(bfhip_engine *e, int filter, int coeff);          /* fctrl.coeff */
+int bfhip_engine_set_delayblocks(bfhip_engine *e, int filter, int blocks);   /* .delayblocks */
+int bfhip_engine_set_scale(bfhip_engine *e, int filter, int io, int index, double scale);
+int bfhip_engine_set_fscale(bfhip_engine *e, int filter, int index, double scale);
+
+/* ---- per block ------------------------------------------------------------------------ */
+
+/* Host buffers (what filter_process() holds: inbuf[curbuf], outbuf[curbuf]).  Copies in,
+   runs the block, copies out, waits.  Returns status bits (>= 0) or an error (< 0).
+   overflow[] (may be NULL): n_out structs, read-modify-written like bfrun.c:1929-1936. */
+int bfhip_engine_block(bfhip_engine *e, const void *rawin, void *rawout,
+                       bfhip_overflow overflow[]);
+
+/* Device-resident raw buffers, asynchronous on the engine's stream. */
+int bfhip_engine_block_dev(bfhip_engine *e, const void *rawin_dev, void *rawout_dev);
+/* wait for the stream; returns accumulated status bits (and clears them) or an error */
+int bfhip_engine_sync(bfhip_engine *e);
+
+/* The three phases of a block, for a host that shards the crossbar over several GPUs and
+   puts a collective between them ("multi-GPU"):
+     inputs : raw -> real -> FFT -> ring slot, for this engine's input channels
+     mac    : Z[o] = sum over this engine's filters (partial sums if inputs are sharded);
+              z_dev: n_out * L complex numbers of the working precision, channel-major
+     outputs: inverse FFT + real -> raw of channels [first, first+count) from z_dev, whose
+              channel 0 is output `first` */
+int bfhip_engine_inputs_dev(bfhip_engine *e, const void *rawin_dev);
+int bfhip_engine_mac_dev(bfhip_engine *e, void *z_dev);
+int bfhip_engine_outputs_dev(bfhip_engine *e, const void *z_dev, int first, int count,
+                             void *rawout_dev);
+/* advance blockcounter / curbuf (bfrun.c:2031-2034); block/block_dev do it themselves */
+int bfhip_engine_advance(bfhip_engine *e);
+
+/* hipStream_t to run on (default: a stream owned by the engine) */
+int bfhip_engine_set_stream(bfhip_engine *e, void *hip_stream);
+
+int bfhip_engine_get_overflow(bfhip_engine *e, int out_channel, bfhip_overflow *of);
+int bfhip_engine_reset_overflow(bfhip_engine *e);     /* bf_reset_peak(), bfrun.c */
+unsigned int bfhip_engine_blockcounter(const bfhip_engine *e);
+
+/* ---- measurement ----------------------------------------------------------------------- */
+
+/* HIP-event timing of the three kernels of a block on the engine's stream.  ms[0..2] =
+   mean duration of the input-FFT, MAC and output-IFFT launches since the last reset,
+   ms[3] = launches averaged.  Reading synchronises the stream. */
+int bfhip_engine_enable_timing(bfhip_engine *e, int on);
+int bfhip_engine_get_timing(bfhip_engine *e, double ms[4]);
+/* algorithmic bytes of one block per SURVEY 8(d): bytes[0] total, [1] MAC kernel only
+   (coefficient partitions + ring slots read + output spectra written) */
+int bfhip_engine_algorithmic_bytes(bfhip_engine *e, double bytes[2]);
+
+/* debug / parity taps: copy device state to host memory */
+int bfhip_engine_read_output_spectrum(bfhip_engine *e, int out_channel, void *dst_complex);
+int bfhip_engine_read_ring_slot(bfhip_engine *e, int in_channel, int slot, void *dst_complex);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,65 @@
+"""Shared builders: the same configuration is instantiated in the oracle (oracle/bforacle.py)
+and in the HIP engine (brutefir_amd.Engine) -- both expose the same methods -- and driven with
+the same seeded raw input blocks."""
+import numpy as np
+
+RAW_NP = {"S8": np.int8, "S16_LE": np.int16, "S32_LE": np.int32, "S24_4LE": np.int32,
+          "FLOAT_LE": np.float32, "FLOAT64_LE": np.float64}
+
+
+def make_ir(rng, taps, n_in):
+    """white noise * exponential decay, normalised so that n_in summed filters stay inside
+    +-1 (synthetic inputs)"""
+    h = rng.standard_normal(taps) * np.exp(-np.arange(taps) / (taps / 6.0))
+    return h / (np.abs(h).sum() * n_in)
+
+
+def crossbar(engine_cls, L, N, rs, I, O, infmt="S24_4LE", outfmt="S24_4LE", seed=4321,
+             taps=None, delays=None, in_scale=None, out_scale=None, **kw):
+    """I x O full crossbar with independent IRs (configs B and C are this shape)."""
+    e = engine_cls(L, N, rs, I, O, **kw)
+    e.set_interleaved(0, infmt)
+    e.set_interleaved(1, outfmt)
+    taps = L * N if taps is None else taps
+    irs = {}
+    for o in range(O):
+        for i in range(I):
+            rng = np.random.default_rng(seed + o * I + i)
+            h = make_ir(rng, taps, I)
+            irs[(o, i)] = h
+            c = e.add_coeff(h)
+            e.add_filter(in_ch=[i], out_ch=[o], coeff=c,
+                         in_scale=[1.0 if in_scale is None else in_scale[o][i]],
+                         out_scale=[1.0 if out_scale is None else out_scale[o][i]],
+                         delayblocks=0 if delays is None else delays[o][i])
+    if hasattr(e, "finalize"):
+        e.finalize()
+    return e, irs
+
+
+def raw_blocks(seed, n_blocks, L, n_ch, fmt, amplitude=0.1):
+    """seeded noise, frames x channels interleaved, in the raw sample format"""
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((n_blocks * L, n_ch)) * amplitude
+    if fmt.startswith("FLOAT"):
+        raw = x.astype(RAW_NP[fmt])
+    else:
+        bits = {"S8": 8, "S16_LE": 16, "S24_4LE": 24, "S32_LE": 32}[fmt]
+        raw = np.clip(np.round(x * (1 << (bits - 1))), -(1 << (bits - 1)), (1 << (bits - 1)) - 1)
+        raw = raw.astype(RAW_NP[fmt])
+    return [np.ascontiguousarray(raw[b * L:(b + 1) * L]) for b in range(n_blocks)]
+
+
+def run(engine, blocks):
+    outs, sts = [], []
+    for b in blocks:
+        st, raw = engine.block(b)
+        sts.append(st)
+        outs.append(raw)
+    return sts, outs
+
+
+def rel_rms(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.sqrt(((a - b) ** 2).sum() / max((b ** 2).sum(), 1e-300)))
