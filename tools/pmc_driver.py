@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Minimal driver for rocprofv3 --pmc passes: runs a few steady-state blocks of a workload
+through the C ABI with host buffers only (no torch in the process -- rocprofv3's counter
+collection crashed with torch loaded on this pool).  Coefficient VALUES are irrelevant for
+traffic, so one seeded IR is reused for every filter (each still gets its own HBM copy).
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out -- \
+        python3 tools/pmc_driver.py C 3
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import brutefir_amd as bf  # noqa: E402
+
+WL = {"C": (64, 64, 8192, 32), "B": (8, 8, 8192, 8), "S": (16, 16, 8192, 32)}
+
+
+def main():
+    name = sys.argv[1] if len(sys.argv) > 1 else "C"
+    steady = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    I, O, L, N = WL[name]
+    e = bf.Engine(L, N, 4, I, O)
+    e.set_interleaved(bf.IN, "S24_4LE")
+    e.set_interleaved(bf.OUT, "S24_4LE")
+    rng = np.random.default_rng(5)
+    h = rng.standard_normal(L * N) * np.exp(-np.arange(L * N) / (L * N / 6.0))
+    h = (h / (np.abs(h).sum() * I)).astype(np.float32)
+    for o in range(O):
+        for i in range(I):
+            e.add_filter(in_ch=[i], out_ch=[o], coeff=e.add_coeff(h))
+    e.finalize()
+    raw = (rng.standard_normal((L, I)) * 0.1 * 8388608).astype(np.int32)
+    for _ in range(N + steady):
+        st, _out = e.block(raw)
+        assert st == 0
+    print("pmc_driver: %s done, %d blocks, alg bytes %s" % (name, N + steady, e.algorithmic_bytes()))
+
+
+if __name__ == "__main__":
+    main()
