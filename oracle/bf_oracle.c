@@ -361,6 +361,7 @@ typedef struct {
     void *ocbuf;        /* ocbuf[n]     */
     void *evalbuf;      /* 1.5 cbuf     */
     int prevcoeff;
+    int procblocks;     /* bfrun.c:1084, 1567-1571 */
 } ofilter;
 
 typedef struct {
@@ -606,6 +607,7 @@ bfo_engine_block(bfo_engine *e, const void *rawin, void *rawout)
         void *mix_in[f->n_in_ch + 1];
         double scales[f->n_in_ch + 1];
 
+        if (f->procblocks < e->N) f->procblocks++;            /* :1567-1569 */
         if (delay < 0) delay = 0; else if (delay > e->N - 1) delay = e->N - 1;
         cblocks = blocks_of(e, coeff, delay);
         prevcblocks = blocks_of(e, prev, delay);
@@ -646,8 +648,10 @@ bfo_engine_block(bfo_engine *e, const void *rawin, void *rawout)
             }
             if (coeff >= 0) {
                 bfo_convolve(c, f->ring[rslot], e->co[coeff].part[0], f->ocbuf);
-                /* the procblocks guard (:1745) only skips slots that are still zero */
-                for (i = 1; i < cblocks; i++) {
+                /* :1745: never reach further back than blocks processed so far (with
+                   N not a power of two the unsigned wrap of t - i would otherwise land
+                   on a live slot) */
+                for (i = 1; i < cblocks && i < f->procblocks; i++) {
                     const int j = (int)((t - (unsigned int)i) % N);
                     bfo_convolve_add(c, f->ring[j], e->co[coeff].part[i], f->ocbuf);
                 }
@@ -655,7 +659,7 @@ bfo_engine_block(bfo_engine *e, const void *rawin, void *rawout)
                 bfo_dirac_convolve(c, f->ring[rslot], f->ocbuf);
             }
             if (fading && prev >= 0) {
-                for (i = 1; i < prevcblocks; i++) {
+                for (i = 1; i < prevcblocks && i < f->procblocks; i++) {      /* :1758 */
                     const int j = (int)((t - (unsigned int)i) % N);
                     bfo_convolve_add(c, f->ring[j], e->co[prev].part[i], e->xfade[0]);
                 }

@@ -1,0 +1,166 @@
+"""CPU: the block-level oracle (one filter_process() iteration, bfrun.c:1420-2083) against an
+independent numpy linear-convolution model and analytic known-answer tests for every
+bookkeeping rule the fused device path has to reproduce."""
+import numpy as np
+import pytest
+
+import bforacle as bo
+import cases
+
+
+def _run_float(e, x, L, O, rs):
+    dt = np.float32 if rs == 4 else np.float64
+    outs = []
+    for b in range(len(x) // L):
+        st, raw = e.block(x[b * L:(b + 1) * L])
+        assert st == 0
+        outs.append(np.frombuffer(raw.tobytes(), dt).reshape(L, O))
+    return np.concatenate(outs).astype(np.float64)
+
+
+@pytest.mark.parametrize("rs,tol", [(4, 2e-6), (8, 1e-13)])
+@pytest.mark.parametrize("L,N,I,O", [(64, 4, 2, 2), (32, 13, 3, 2)])      # 13: bench4's odd N
+def test_crossbar_is_linear_convolution(rs, tol, L, N, I, O):
+    ofmt = "FLOAT_LE" if rs == 4 else "FLOAT64_LE"
+    e, irs = cases.crossbar(bo.Engine, L, N, rs, I, O, "S16_LE", ofmt)
+    nblk = 2 * N + 3
+    x = np.concatenate(cases.raw_blocks(5, nblk, L, I, "S16_LE"))
+    y = _run_float(e, x, L, O, rs)
+    xs = x.astype(np.float64) / 32768.0
+    dt = np.float32 if rs == 4 else np.float64
+    want = np.zeros_like(y)
+    for (o, i), h in irs.items():
+        want[:, o] += np.convolve(xs[:, i], h.astype(dt).astype(np.float64))[:len(x)]
+    assert cases.rel_rms(y, want) <= tol
+
+
+def test_scales_polarity_and_attenuation():
+    """per-input scale incl. polarity flip (bench4 `0//-1`) and output scale"""
+    L, N = 64, 2
+    e = bo.Engine(L, N, 8, 2, 1)
+    e.set_interleaved(0, "FLOAT64_LE")
+    e.set_interleaved(1, "FLOAT64_LE")
+    e.add_filter(in_ch=[0, 1], in_scale=[-1.0, 0.25], out_ch=[0], out_scale=[2.0], coeff=-1)
+    x = np.random.default_rng(0).standard_normal((4 * L, 2))
+    y = _run_float(e, x, L, 1, 8)[:, 0]
+    assert np.abs(y - 2.0 * (-x[:, 0] + 0.25 * x[:, 1])).max() < 1e-12
+
+
+def test_delayed_dirac_hits_the_right_partition_and_delayblocks_shift():
+    L, N = 32, 6
+    for part, off, dly in [(0, 0, 0), (2, 5, 0), (3, 31, 2), (1, 7, 9)]:   # 9 clamps to N-1
+        e = bo.Engine(L, N, 8, 1, 1)
+        e.set_interleaved(0, "FLOAT64_LE")
+        e.set_interleaved(1, "FLOAT64_LE")
+        taps = np.zeros(L * N)
+        taps[part * L + off] = 1.0
+        c = e.add_coeff(taps)
+        e.add_filter(in_ch=[0], out_ch=[0], coeff=c, delayblocks=dly)
+        x = np.random.default_rng(part).standard_normal((3 * N * L, 1))
+        y = _run_float(e, x, L, 1, 8)[:, 0]
+        d_eff = min(max(dly, 0), N - 1)
+        # cblocks = min(coeff blocks, N - delay): partitions beyond it are dropped
+        if part >= N - d_eff:
+            assert np.abs(y).max() == 0.0
+            continue
+        sh = part * L + off + d_eff * L
+        assert np.abs(y[sh:] - x[:len(x) - sh, 0]).max() < 1e-12
+        assert sh == 0 or np.abs(y[:sh]).max() < 1e-12
+
+
+def test_short_coeff_set_uses_its_own_block_count():
+    L, N = 32, 8
+    e = bo.Engine(L, N, 8, 1, 1)
+    e.set_interleaved(0, "FLOAT64_LE")
+    e.set_interleaved(1, "FLOAT64_LE")
+    h = np.random.default_rng(1).standard_normal(3 * L)
+    c = e.add_coeff(h, n_blocks=3)                           # `blocks: 3`
+    e.add_filter(in_ch=[0], out_ch=[0], coeff=c)
+    x = np.random.default_rng(2).standard_normal((12 * L, 1))
+    y = _run_float(e, x, L, 1, 8)[:, 0]
+    assert np.abs(y - np.convolve(x[:, 0], h)[:len(x)]).max() < 1e-11
+    with pytest.raises(ValueError):
+        e.add_coeff(np.zeros(9 * L), n_blocks=9)             # longer than N: rejected
+
+
+def test_bench1_topology_cascade_of_diracs_is_identity():
+    """bench1_config: two input filters feed two cascaded filters (from_filters), all dirac:
+    both outputs = in0 + in1 (SURVEY B.5 i)"""
+    L, N = 64, 8
+    e = bo.Engine(L, N, 4, 2, 2)
+    e.set_interleaved(0, "S24_4LE")
+    e.set_interleaved(1, "S24_4LE")
+    d = np.zeros(L * N)
+    d[0] = 1.0
+    c = e.add_coeff(d)
+    f0 = e.add_filter(in_ch=[0], coeff=c)
+    f1 = e.add_filter(in_ch=[1], coeff=c)
+    e.add_filter(in_f=[f0, f1], out_ch=[0], coeff=c)
+    e.add_filter(in_f=[f0, f1], out_ch=[1], coeff=c)
+    x = np.concatenate(cases.raw_blocks(3, 12, L, 2, "S24_4LE", amplitude=0.05))
+    outs = []
+    for b in range(12):
+        st, raw = e.block(x[b * L:(b + 1) * L])
+        assert st == 0
+        outs.append(raw.view(np.int32).reshape(L, 2))
+    y = np.concatenate(outs).astype(np.int64)
+    want = x[:, 0].astype(np.int64) + x[:, 1]
+    for ch in range(2):
+        assert np.abs(y[:, ch] - want).max() <= 2             # f32 rounding, 24-bit LSBs
+
+
+def test_crossfade_switch_sequence():
+    """coefficient switch with crossfade: the switch block is (1-w)*old + w*new with
+    w = n/(L-1); afterwards ALL partitions use the new IR at once (SURVEY B.5 iv)"""
+    L, N = 32, 4
+    rng = np.random.default_rng(8)
+    ha, hb = rng.standard_normal(L * N) * 0.1, rng.standard_normal(L * N) * 0.1
+    e = bo.Engine(L, N, 8, 1, 1)
+    e.set_interleaved(0, "FLOAT64_LE")
+    e.set_interleaved(1, "FLOAT64_LE")
+    ca, cb = e.add_coeff(ha), e.add_coeff(hb)
+    f = e.add_filter(in_ch=[0], out_ch=[0], coeff=ca, crossfade=True)
+    nblk = 10
+    x = rng.standard_normal((nblk * L, 1))
+    ya = np.convolve(x[:, 0], ha)[:nblk * L]
+    yb = np.convolve(x[:, 0], hb)[:nblk * L]
+    w = np.arange(L) / (L - 1.0)
+    for b in range(nblk):
+        if b == 5:
+            e.set_coeff(f, cb)
+        st, raw = e.block(x[b * L:(b + 1) * L])
+        y = raw.view(np.float64)
+        s = slice(b * L, (b + 1) * L)
+        want = ya[s] if b < 5 else (ya[s] * (1 - w) + yb[s] * w if b == 5 else yb[s])
+        assert np.abs(y - want).max() < 1e-11, b
+
+
+def test_overflow_accounting_and_clipping():
+    L = 64
+    e = bo.Engine(L, 1, 8, 1, 1)
+    e.set_interleaved(0, "FLOAT64_LE")
+    e.set_interleaved(1, "S16_LE")
+    e.add_filter(in_ch=[0], out_ch=[0], coeff=-1)
+    x = np.zeros((L, 1))
+    x[3], x[10], x[11] = 1.5, -2.0, 0.25
+    st, raw = e.block(x)
+    y = raw.view(np.int16)
+    assert st == 0 and y[3] == 32767 and y[10] == -32768 and y[11] == 8192
+    of = e.overflow(0)
+    assert of.n_overflows == 2 and of.intlargest == 8192 and of.max == 32767.0
+    assert of.largest == pytest.approx(2.0 * 32768 - 0.5)      # |v| after the +0.5 offset
+
+
+def test_nan_and_safety_limit_are_reported():
+    L = 64
+    e = bo.Engine(L, 1, 4, 1, 1)
+    e.set_interleaved(0, "FLOAT_LE")
+    e.set_interleaved(1, "FLOAT_LE")
+    e.add_filter(in_ch=[0], out_ch=[0], coeff=-1)
+    e.set_safety_limit(2.0)
+    x = np.zeros((L, 1), np.float32)
+    assert e.block(x)[0] == 0
+    x[5] = 3.0
+    assert e.block(x)[0] == 2                   # reference: bf_exit (real2raw.h:32-41)
+    x[5] = np.nan
+    assert e.block(x)[0] == 1                   # reference: abort() (real2raw.h:24-31)

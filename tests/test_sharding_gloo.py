@@ -1,0 +1,86 @@
+"""CPU, world_size 2 over gloo: the multi-GPU decomposition (brutefir_amd/sharding.py).
+Each rank owns half of the inputs and computes partial output spectra for ALL outputs; one
+mix-down collective leaves each rank the finished spectra of its half of the outputs.  The
+partial spectra are produced by the oracle here (the HIP engine needs a GPU); what is under
+test is the sharding arithmetic and the collective plumbing bench.py uses."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "oracle"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    import bforacle as bo
+    import cases
+    from brutefir_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    L, N, I, O = 64, 4, 4, 4
+    fi, ci, fo, co = sharding.shard_crossbar(I, O, world, rank)
+    # this rank's engine: its inputs only, all outputs; same IR seeds as the full crossbar
+    e = bo.Engine(L, N, 8, ci, O)
+    fm = bo.interleaved_formats("FLOAT64_LE", I)
+    for c in range(ci):
+        e.set_format(0, c, fm[fi + c])
+    for c, f in enumerate(bo.interleaved_formats("FLOAT64_LE", O)):
+        e.set_format(1, c, f)
+    for o in range(O):
+        for i in range(fi, fi + ci):
+            h = cases.make_ir(np.random.default_rng(4321 + o * I + i), L * N, I)
+            e.add_filter(in_ch=[i - fi], out_ch=[o], coeff=e.add_coeff(h))
+    full, _ = cases.crossbar(bo.Engine, L, N, 8, I, O, "FLOAT64_LE", "FLOAT64_LE")
+    worst = 0.0
+    for blk in cases.raw_blocks(11, N + 2, L, I, "FLOAT64_LE"):
+        e.block(blk)
+        full.block(blk)
+        zp = np.stack([e.output_spectrum(o) for o in range(O)])           # partial, all outputs
+        z_part = torch.from_numpy(zp.copy())
+        z_loc = torch.zeros(co, 2 * L, dtype=torch.float64)
+        sharding.mixdown(z_part, z_loc)
+        want = np.stack([full.output_spectrum(o) for o in range(fo, fo + co)])
+        worst = max(worst, float(np.abs(z_loc.numpy() - want).max() / np.abs(want).max()))
+    dist.destroy_process_group()
+    q.put((rank, worst))
+
+
+def test_input_sharded_crossbar_mixdown_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, worst in res:
+        assert worst < 1e-12, (rank, worst)
+
+
+def test_shard_arithmetic():
+    from brutefir_amd import sharding
+    assert sharding.shard_crossbar(64, 64, 8, 3) == (24, 8, 24, 8)
+    assert sharding.shard_crossbar(64, 64, 1, 0) == (0, 64, 0, 64)
+    with pytest.raises(ValueError):
+        sharding.shard_crossbar(26, 26, 8, 0)
