@@ -104,6 +104,22 @@ struct bfhip_engine {
     void *d_taps = nullptr;
     size_t taps_cap = 0;
 
+    // filters that need more than the shared-ring fast path (SURVEY A3 N-way mix, A7, A8)
+    std::vector<int> level, owner_index, y_index, sink_index, fade_index;
+    std::vector<char> is_source;
+    int n_levels = 0, n_owners = 0, n_y = 0, n_sinks = 0, n_fadeable = 0;
+    void *d_fring = nullptr;       // [n_owners][N][L] complex: private rings
+    void *d_Y = nullptr;           // [n_y][L] complex: materialised filter outputs
+    void *d_Yold = nullptr;        // [n_fadeable][L] complex: old-coefficient result in a fade block
+    void *d_evalprev = nullptr;    // [n_sinks][L] real: previous valid half (convolve_eval state)
+    void *d_jobs = nullptr;        // fill jobs | mix sources | filter jobs | fade jobs
+    size_t jobs_cap = 0;
+    struct LevelJobs { size_t fill_off = 0; int n_fill = 0; size_t filt_off = 0; int n_filt = 0;
+                       size_t fade_off = 0; int n_fade = 0; };
+    std::vector<LevelJobs> level_jobs;
+    size_t src_off = 0;
+    bool any_fading = false;
+
     // plan geometry
     int n_groups = 0, n_out_padded = 0, n_chunks = 1, n_tiles = 1, mac_threads = 256;
     int n_entries = 0;
@@ -207,6 +223,38 @@ void launch_sum(bfhip_engine *e, const void *Zp, void *Z, hipError_t *err) {
     *err = hipGetLastError();
 }
 
+template <typename T, int LOG2L>
+void launch_levels(bfhip_engine *e, hipError_t *err) {
+    constexpr int NT = fft_threads(LOG2L);
+    const size_t lds = sizeof(c2<T>) << LOG2L;
+    auto kf = ring_fill_kernel<T, LOG2L>;
+    auto kx = crossfade_kernel<T, LOG2L>;
+    const unsigned long long age64 = std::min<unsigned long long>(e->blocks_done + 1, (unsigned long long)e->N);
+    const unsigned char *base = (const unsigned char *)e->d_jobs;
+    const int V = 16 / (int)sizeof(c2<T>);
+    const int threads = e->mac_threads;
+    const int tiles = (e->L + threads * V - 1) / (threads * V);
+    for (auto &lj : e->level_jobs) {
+        if (lj.n_fill > 0) {
+            if ((*err = allow_lds(kf, lds)) != hipSuccess) return;
+            hipLaunchKernelGGL(kf, dim3(lj.n_fill), dim3(NT), lds, e->stream,
+                               (const FillJob<T> *)(base + lj.fill_off),
+                               (const MixSrc<T> *)(base + e->src_off), (const c2<T> *)e->d_tw,
+                               e->N, e->blockcounter);
+        }
+        if (lj.n_filt > 0) {
+            hipLaunchKernelGGL(mac_filter_kernel<T>, dim3(tiles, lj.n_filt), dim3(threads), 0, e->stream,
+                               (const FilterJob<T> *)(base + lj.filt_off), e->L, e->blockcounter, (int)age64);
+        }
+        if (lj.n_fade > 0) {
+            if ((*err = allow_lds(kx, lds)) != hipSuccess) return;
+            hipLaunchKernelGGL(kx, dim3(lj.n_fade), dim3(NT), lds, e->stream,
+                               (const FadeJob<T> *)(base + lj.fade_off), (const c2<T> *)e->d_tw);
+        }
+        if ((*err = hipGetLastError()) != hipSuccess) return;
+    }
+}
+
 // ---------------------------------------------------------------- plan
 
 int clamp_delay(const bfhip_engine *e, int d) {          // bfrun.c:1579-1584
@@ -222,31 +270,109 @@ int cblocks_of(const bfhip_engine *e, int coeff, int delay) {   // bfrun.c:1585-
 
 template <typename T>
 int build_plan_t(bfhip_engine *e) {
-    const int O = e->n_ch[1];
+    const int O = e->n_ch[1], I = e->n_ch[0], F = (int)e->filters.size();
+    const size_t L = e->L;
     e->n_groups = (O + OG - 1) / OG;
     e->n_out_padded = e->n_groups * OG;
     std::vector<std::vector<MacEntry<T>>> per_group(e->n_groups);
-    std::vector<std::map<std::pair<int, int>, std::vector<int>>> index(e->n_groups);
+    std::vector<std::map<std::pair<long, int>, std::vector<int>>> index(e->n_groups);
     double bytes_H = 0, bytes_ring = 0;
-    std::vector<char> ring_used((size_t)e->n_ch[0] * e->N, 0);
+    // ring id: 0..I-1 input rings, I+f private ring of filter f, I+F+f materialised Y_f
+    std::map<long, std::vector<char>> ring_used;
 
-    for (size_t fi = 0; fi < e->filters.size(); fi++) {
+    std::vector<std::vector<FillJob<T>>> fills(e->n_levels);
+    std::vector<std::vector<FilterJob<T>>> filts(e->n_levels);
+    std::vector<std::vector<FadeJob<T>>> fades(e->n_levels);
+    std::vector<MixSrc<T>> srcs;
+    e->any_fading = false;
+
+    auto Yptr = [&](int f) { return (c2<T> *)e->d_Y + (size_t)e->y_index[f] * L; };
+
+    for (int fi = 0; fi < F; fi++) {
         const Filter &f = e->filters[fi];
-        if (f.in_ch.size() != 1 || !f.in_f.empty()) {
-            return fail(BFHIP_EINVAL, "filter %zu: only single-input filters are supported by this "
-                        "build of the device plan", fi);
-        }
-        if (f.coeff >= (int)e->coeffs.size()) return fail(BFHIP_EINVAL, "filter %zu: bad coeff", fi);
-        const int ch = f.in_ch[0];
+        if (f.coeff >= (int)e->coeffs.size()) return fail(BFHIP_EINVAL, "filter %d: bad coeff", fi);
         const int delay = clamp_delay(e, f.delayblocks);
         const int P = f.coeff < 0 ? 1 : cblocks_of(e, f.coeff, delay);
-        const double s_in = f.in_scale[0] * e->fmt[0][ch].scale;          // bfrun.c:1664
-        for (int p = 0; p < P; p++) ring_used[(size_t)ch * e->N + ((p + delay) % e->N)] = 1;
+        const bool owner = e->owner_index[fi] >= 0;
+        const bool fading = f.crossfade && f.prevcoeff != f.coeff;
+        const bool needY = e->is_source[fi] || fading;
+        if (fading) e->any_fading = true;
+        if (needY && e->y_index[fi] < 0) return fail(BFHIP_ESTATE, "filter %d: no output buffer reserved", fi);
+
+        // where this filter's history lives and how to index it
+        const c2<T> *ring;
+        long ring_id;
+        int rdelay;
+        double rscale;
+        if (owner) {
+            ring = (const c2<T> *)e->d_fring + (size_t)e->owner_index[fi] * e->N * L;
+            ring_id = I + fi; rdelay = 0; rscale = 1.0;
+            FillJob<T> job;
+            memset(&job, 0, sizeof(job));
+            job.ring = (c2<T> *)ring;
+            job.delay = delay;
+            job.n_in = (int)f.in_ch.size();
+            job.in_off = (int)srcs.size();
+            for (size_t i = 0; i < f.in_ch.size(); i++) {
+                MixSrc<T> m;
+                m.spec = (const c2<T> *)e->d_ring + (size_t)f.in_ch[i] * e->N * L;
+                m.scale = (T)(f.in_scale[i] * e->fmt[0][f.in_ch[i]].scale);      // bfrun.c:1641
+                m.R = e->N;
+                srcs.push_back(m);
+            }
+            job.n_up = (int)f.in_f.size();
+            job.up_off = (int)srcs.size();
+            for (size_t i = 0; i < f.in_f.size(); i++) {
+                MixSrc<T> m;
+                m.spec = Yptr(f.in_f[i]);
+                m.scale = (T)f.in_fscale[i];
+                m.R = 1;
+                srcs.push_back(m);
+            }
+            job.evalprev = job.n_up > 0 ? (T *)e->d_evalprev + (size_t)e->sink_index[fi] * L : nullptr;
+            fills[e->level[fi]].push_back(job);
+        } else {
+            const int ch = f.in_ch[0];
+            ring = (const c2<T> *)e->d_ring + (size_t)ch * e->N * L;
+            ring_id = ch; rdelay = delay;
+            rscale = f.in_scale[0] * e->fmt[0][ch].scale;                         // bfrun.c:1664
+        }
+        {
+            auto &u = ring_used[ring_id];
+            u.resize(e->N, 0);
+            for (int p = 0; p < P; p++) u[(p + rdelay) % e->N] = 1;
+        }
+
+        if (needY) {
+            FilterJob<T> job;
+            job.ring = ring; job.R = e->N; job.delay = rdelay; job.scale = (T)rscale;
+            job.H = f.coeff < 0 ? nullptr : (const c2<T> *)e->coeffs[f.coeff].d_H;
+            job.P = P; job.kind = f.coeff < 0 ? TERM_DIRAC : TERM_COEFF;
+            job.Y = Yptr(fi);
+            filts[e->level[fi]].push_back(job);
+            if (f.coeff >= 0) bytes_H += (double)P * L * sizeof(c2<T>);
+            if (fading) {
+                // old-coefficient result for the fade (bfrun.c:1726-1769, 1803-1827)
+                FilterJob<T> old = job;
+                const int pc = f.prevcoeff;
+                old.H = pc < 0 ? nullptr : (const c2<T> *)e->coeffs[pc].d_H;
+                old.P = pc < 0 ? 1 : cblocks_of(e, pc, delay);
+                old.kind = pc < 0 ? TERM_DIRAC : TERM_COEFF;
+                old.Y = (c2<T> *)e->d_Yold + (size_t)e->fade_index[fi] * L;
+                filts[e->level[fi]].push_back(old);
+                FadeJob<T> fj;
+                fj.Ynew = job.Y; fj.Yold = old.Y;
+                fades[e->level[fi]].push_back(fj);
+            }
+        }
+
         for (size_t oi = 0; oi < f.out_ch.size(); oi++) {
             const int o = f.out_ch[oi];
             const int g = o / OG, j = o % OG;
-            const double s_out = f.out_scale[oi] / e->fmt[1][o].scale;    // bfrun.c:1850
-            auto &slots = index[g][{ch, delay}];
+            const double s_out = f.out_scale[oi] / e->fmt[1][o].scale;            // bfrun.c:1850
+            const std::pair<long, int> key = needY ? std::make_pair((long)(I + F + fi), 0)
+                                                   : std::make_pair(ring_id, rdelay);
+            auto &slots = index[g][key];
             int ei = -1;
             for (int cand : slots) {
                 if (per_group[g][cand].term[j].kind == TERM_NONE) { ei = cand; break; }
@@ -254,21 +380,25 @@ int build_plan_t(bfhip_engine *e) {
             if (ei < 0) {
                 MacEntry<T> ne;
                 memset(&ne, 0, sizeof(ne));
-                ne.ring = (const c2<T> *)e->d_ring + (size_t)ch * e->N * e->L;
-                ne.R = e->N;
-                ne.delay = delay;
+                ne.ring = needY ? Yptr(fi) : ring;
+                ne.R = needY ? 1 : e->N;
+                ne.delay = needY ? 0 : rdelay;
                 for (int q = 0; q < OG; q++) ne.term[q].kind = TERM_NONE;
                 per_group[g].push_back(ne);
                 ei = (int)per_group[g].size() - 1;
                 slots.push_back(ei);
             }
             MacTerm<T> &tm = per_group[g][ei].term[j];
-            tm.kind = f.coeff < 0 ? TERM_DIRAC : TERM_COEFF;
-            tm.H = f.coeff < 0 ? nullptr : (const c2<T> *)e->coeffs[f.coeff].d_H;
-            tm.P = P;
-            tm.scale = (T)(s_in * s_out);
-            per_group[g][ei].maxP = std::max(per_group[g][ei].maxP, P);
-            if (f.coeff >= 0) bytes_H += (double)P * e->L * sizeof(c2<T>);
+            if (needY) {
+                tm.kind = TERM_IDENT; tm.H = nullptr; tm.P = 1; tm.scale = (T)s_out;
+            } else {
+                tm.kind = f.coeff < 0 ? TERM_DIRAC : TERM_COEFF;
+                tm.H = f.coeff < 0 ? nullptr : (const c2<T> *)e->coeffs[f.coeff].d_H;
+                tm.P = P;
+                tm.scale = (T)(rscale * s_out);
+                if (f.coeff >= 0) bytes_H += (double)P * L * sizeof(c2<T>);
+            }
+            per_group[g][ei].maxP = std::max(per_group[g][ei].maxP, tm.P);
         }
     }
 
@@ -278,7 +408,8 @@ int build_plan_t(bfhip_engine *e) {
     e->n_tiles = (e->L + bins_per_wg - 1) / bins_per_wg;
     size_t max_entries = 1;
     for (auto &v : per_group) max_entries = std::max(max_entries, v.size());
-    const int target_wgs = 4096;
+    int target_wgs = 4096;
+    if (const char *env = getenv("BFHIP_MAC_TARGET_WGS")) target_wgs = std::max(1, atoi(env));
     int S = (target_wgs + e->n_tiles * e->n_groups - 1) / (e->n_tiles * e->n_groups);
     S = std::max(1, std::min<int>(S, (int)max_entries));
     e->n_chunks = S;
@@ -304,6 +435,26 @@ int build_plan_t(bfhip_engine *e) {
     }
     e->n_entries = (int)flat.size();
 
+    // job arrays for the levelled (non fast-path) filters, one device blob
+    std::vector<unsigned char> blob;
+    auto append = [&](const void *p, size_t n) {
+        const size_t off = (blob.size() + 15) & ~(size_t)15;
+        blob.resize(off + n);
+        if (n) memcpy(blob.data() + off, p, n);
+        return off;
+    };
+    e->src_off = append(srcs.data(), srcs.size() * sizeof(MixSrc<T>));
+    e->level_jobs.assign(e->n_levels, bfhip_engine::LevelJobs());
+    for (int lv = 0; lv < e->n_levels; lv++) {
+        auto &lj = e->level_jobs[lv];
+        lj.n_fill = (int)fills[lv].size();
+        lj.fill_off = append(fills[lv].data(), fills[lv].size() * sizeof(FillJob<T>));
+        lj.n_filt = (int)filts[lv].size();
+        lj.filt_off = append(filts[lv].data(), filts[lv].size() * sizeof(FilterJob<T>));
+        lj.n_fade = (int)fades[lv].size();
+        lj.fade_off = append(fades[lv].data(), fades[lv].size() * sizeof(FadeJob<T>));
+    }
+
     // upload
     const size_t eb = std::max<size_t>(flat.size(), 1) * sizeof(MacEntry<T>);
     if (eb > e->entries_cap) {
@@ -317,10 +468,16 @@ int build_plan_t(bfhip_engine *e) {
         HIPCHK(hipMalloc((void **)&e->d_chunks, cb));
         e->chunks_cap = cb;
     }
+    if (blob.size() > e->jobs_cap) {
+        if (e->d_jobs) (void)hipFree(e->d_jobs);
+        HIPCHK(hipMalloc(&e->d_jobs, blob.size()));
+        e->jobs_cap = blob.size();
+    }
     HIPCHK(hipStreamSynchronize(e->stream));
     if (!flat.empty()) HIPCHK(hipMemcpy(e->d_entries, flat.data(), flat.size() * sizeof(MacEntry<T>), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->d_chunks, chunks.data(), cb, hipMemcpyHostToDevice));
-    const size_t zb = (size_t)S * e->n_out_padded * e->L * sizeof(c2<T>);
+    if (!blob.empty()) HIPCHK(hipMemcpy(e->d_jobs, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    const size_t zb = (size_t)S * e->n_out_padded * L * sizeof(c2<T>);
     if (zb > e->zp_bytes) {
         if (e->d_Zp) (void)hipFree(e->d_Zp);
         HIPCHK(hipMalloc(&e->d_Zp, zb));
@@ -328,13 +485,13 @@ int build_plan_t(bfhip_engine *e) {
     }
 
     // algorithmic bytes per block, SURVEY 8(d): C*(F*P + U*P + U + O) + (I+O)*L*s_raw
-    const double C = (double)e->L * sizeof(c2<T>);
-    for (char u : ring_used) bytes_ring += u ? C : 0;
+    const double C = (double)L * sizeof(c2<T>);
+    for (auto &kv : ring_used) for (char u : kv.second) bytes_ring += u ? C : 0;
     double raw = 0;
     for (int io = 0; io < 2; io++)
-        for (auto &f : e->fmt[io]) raw += (double)e->L * f.bytes;
+        for (auto &f : e->fmt[io]) raw += (double)L * f.bytes;
     e->alg_bytes_mac = bytes_H + bytes_ring + C * O;
-    e->alg_bytes_total = e->alg_bytes_mac + C * e->n_ch[0] + raw;
+    e->alg_bytes_total = e->alg_bytes_mac + C * (I + e->n_owners) + raw;
     e->plan_dirty = false;
     return BFHIP_OK;
 }
@@ -402,6 +559,16 @@ int do_inputs(bfhip_engine *e, const void *rawin_dev) {
     return BFHIP_OK;
 }
 
+int do_levels(bfhip_engine *e) {
+    bool any = false;
+    for (auto &lj : e->level_jobs) any = any || lj.n_fill || lj.n_filt || lj.n_fade;
+    if (!any) return BFHIP_OK;
+    hipError_t err = hipSuccess;
+    DISPATCH(launch_levels, e, &err);
+    if (err != hipSuccess) return fail(BFHIP_EHIP, "level kernels: %s", hipGetErrorString(err));
+    return BFHIP_OK;
+}
+
 int do_mac(bfhip_engine *e, void *Zp) {
     hipError_t err = hipSuccess;
     if (e->rs == 4) launch_mac<float>(e, Zp, &err); else launch_mac<double>(e, Zp, &err);
@@ -421,6 +588,8 @@ int do_outputs(bfhip_engine *e, const void *Zp, size_t chunk_stride, int n_chunk
 void advance(bfhip_engine *e) {
     e->blockcounter++;                                   // bfrun.c:2034 (unsigned wrap)
     e->blocks_done++;
+    for (auto &f : e->filters) f.prevcoeff = f.coeff;    // bfrun.c:1838
+    if (e->any_fading) e->plan_dirty = true;             // the fade lasts exactly one block
 }
 
 }  // namespace
@@ -494,7 +663,8 @@ void bfhip_engine_destroy(bfhip_engine *e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (auto &c : e->coeffs) if (c.d_H) (void)hipFree(c.d_H);
     void *ptrs[] = {e->d_tw, e->d_prev, e->d_ring, e->d_fmt[0], e->d_fmt[1], e->d_over, e->d_status,
-                    e->d_bad, e->d_Zp, e->d_entries, e->d_chunks, e->d_rawin, e->d_rawout, e->d_taps};
+                    e->d_bad, e->d_Zp, e->d_entries, e->d_chunks, e->d_rawin, e->d_rawout, e->d_taps,
+                    e->d_fring, e->d_Y, e->d_Yold, e->d_evalprev, e->d_jobs};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto ev : e->ev) (void)hipEventDestroy(ev);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -641,6 +811,35 @@ int bfhip_engine_finalize(bfhip_engine *e) {
     HIPCHK(hipMalloc((void **)&e->d_rawin, e->raw_bytes[0]));
     HIPCHK(hipMalloc((void **)&e->d_rawout, e->raw_bytes[1]));
     HIPCHK(hipMemset(e->d_rawout, 0, e->raw_bytes[1]));
+    // classify filters: who owns a private ring, who must materialise its output
+    {
+        const int F = (int)e->filters.size();
+        e->level.assign(F, 0); e->owner_index.assign(F, -1); e->y_index.assign(F, -1);
+        e->sink_index.assign(F, -1); e->fade_index.assign(F, -1); e->is_source.assign(F, 0);
+        e->n_owners = e->n_y = e->n_sinks = e->n_fadeable = 0;
+        int maxlevel = 0;
+        for (int fi = 0; fi < F; fi++) {
+            const Filter &f = e->filters[fi];
+            for (int g : f.in_f) { e->is_source[g] = 1; e->level[fi] = std::max(e->level[fi], e->level[g] + 1); }
+            maxlevel = std::max(maxlevel, e->level[fi]);
+            if (f.in_ch.size() != 1 || !f.in_f.empty()) e->owner_index[fi] = e->n_owners++;
+            if (!f.in_f.empty()) e->sink_index[fi] = e->n_sinks++;
+            if (f.crossfade) e->fade_index[fi] = e->n_fadeable++;
+        }
+        for (int fi = 0; fi < F; fi++)
+            if (e->is_source[fi] || e->filters[fi].crossfade) e->y_index[fi] = e->n_y++;
+        e->n_levels = maxlevel + 1;
+        auto zalloc = [&](void **p, size_t bytes) -> int {
+            if (bytes == 0) return BFHIP_OK;
+            if (hipMalloc(p, bytes) != hipSuccess) return fail(BFHIP_ENOMEM, "out of device memory (%zu bytes)", bytes);
+            HIPCHK(hipMemset(*p, 0, bytes));
+            return BFHIP_OK;
+        };
+        if ((r = zalloc(&e->d_fring, (size_t)e->n_owners * e->N * L * e->csize())) != BFHIP_OK) return r;
+        if ((r = zalloc(&e->d_Y, (size_t)e->n_y * L * e->csize())) != BFHIP_OK) return r;
+        if ((r = zalloc(&e->d_Yold, (size_t)e->n_fadeable * L * e->csize())) != BFHIP_OK) return r;
+        if ((r = zalloc(&e->d_evalprev, (size_t)e->n_sinks * L * e->rs)) != BFHIP_OK) return r;
+    }
     e->finalized = true;
     r = bfhip_engine_reset_overflow(e);
     if (r != BFHIP_OK) return r;
@@ -690,6 +889,7 @@ int bfhip_engine_inputs_dev(bfhip_engine *e, const void *rawin_dev) {
 int bfhip_engine_mac_dev(bfhip_engine *e, void *z_dev) {
     int r = ensure_ready(e);
     if (r != BFHIP_OK) return r;
+    if ((r = do_levels(e)) != BFHIP_OK) return r;
     if (e->n_chunks == 1 && e->n_out_padded == e->n_ch[1]) return do_mac(e, z_dev);
     r = do_mac(e, e->d_Zp);
     if (r != BFHIP_OK) return r;
@@ -717,6 +917,7 @@ int bfhip_engine_block_dev(bfhip_engine *e, const void *rawin_dev, void *rawout_
     if (r != BFHIP_OK) return r;
     if ((r = record(e, 0)) != BFHIP_OK) return r;
     if ((r = do_inputs(e, rawin_dev)) != BFHIP_OK) return r;
+    if ((r = do_levels(e)) != BFHIP_OK) return r;
     if ((r = record(e, 1)) != BFHIP_OK) return r;
     if ((r = do_mac(e, e->d_Zp)) != BFHIP_OK) return r;
     if ((r = record(e, 2)) != BFHIP_OK) return r;

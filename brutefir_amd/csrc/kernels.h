@@ -309,6 +309,253 @@ sum_partials_kernel(const c2<T> *__restrict__ Zp, c2<T> *__restrict__ Z, size_t 
     Z[i] = a;
 }
 
+// ------------------------------------------------------------------ K4/K5: ring fill (N-way mix + cascade eval)
+
+// A filter that mixes several inputs, or takes other filters' outputs ("from_filters"), owns a
+// private ring exactly like the reference's cbuf[n][N] (bfrun.c:1273-1287).  One workgroup per
+// such filter computes, for block t,
+//     E      = rfft([ y_{t-1} | y_t ]),  y_t = first L samples of irfft( sum_g fscale_g * Y_g )
+//                                         (convolver_convolve_eval, fftw_convolver.c:411-433)
+//     ring[(t + delay) mod N] = sum_i scale_i * X_i[t]  +  1.0 * E      (bfrun.c:1603-1680)
+// with the summation order of mixnscale(INPUT): channel inputs first, the evaluated buffer last.
+template <typename T> struct FillJob {
+    c2<T> *ring;            // [N][L]
+    T *evalprev;            // [L] previous valid half, nullptr when there are no filter inputs
+    int n_in, in_off;       // channel inputs: src[in_off .. in_off + n_in)
+    int n_up, up_off;       // filter inputs
+    int delay, pad;
+};
+
+template <typename T> struct MixSrc {
+    const c2<T> *spec;      // packed spectrum (an input ring's base, or an upstream Y)
+    T scale;
+    int R;                  // ring depth of spec (slot = t mod R), 1 for a Y buffer
+};
+
+template <typename T, int LOG2L>
+__global__ __launch_bounds__(fft_threads(LOG2L)) void
+ring_fill_kernel(const FillJob<T> *__restrict__ jobs, const MixSrc<T> *__restrict__ src,
+                 const c2<T> *__restrict__ tw, int N, unsigned int t) {
+    constexpr int L = 1 << LOG2L, NT = fft_threads(LOG2L);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    c2<T> *s = reinterpret_cast<c2<T> *>(smem);
+    const int tid = threadIdx.x;
+    const FillJob<T> job = jobs[blockIdx.x];
+    c2<T> *dst = job.ring + (size_t)((t + (unsigned int)job.delay) % (unsigned int)N) * L;
+    const MixSrc<T> *in = src + job.in_off;
+    const MixSrc<T> *up = src + job.up_off;
+
+    if (job.n_up > 0) {
+        // M = sum_g fscale_g Y_g (mixnscale OUTPUT order), straight into the C2R pre-pass
+        for (int k = tid; k <= L / 2; k += NT) {
+            c2<T> a = mk<T>(up[0].spec[k].x * up[0].scale, up[0].spec[k].y * up[0].scale);
+            c2<T> b = mk<T>((T)0, (T)0);
+            if (k != 0) b = mk<T>(up[0].spec[L - k].x * up[0].scale, up[0].spec[L - k].y * up[0].scale);
+            for (int g = 1; g < job.n_up; g++) {
+                const c2<T> v = up[g].spec[k];
+                a = mk<T>(a.x + v.x * up[g].scale, a.y + v.y * up[g].scale);
+                if (k != 0) {
+                    const c2<T> w = up[g].spec[L - k];
+                    b = mk<T>(b.x + w.x * up[g].scale, b.y + w.y * up[g].scale);
+                }
+            }
+            if (k == 0) {
+                s[0] = mk<T>(a.x + a.y, a.x - a.y);
+            } else {
+                b = conj(b);
+                const c2<T> e = a + b, d = a - b;
+                const c2<T> o = cmul(d, conj(tw[k]));
+                s[k] = mk<T>(e.x - o.y, e.y + o.x);
+                if (k != L - k) s[L - k] = mk<T>(e.x + o.y, -e.y + o.x);
+            }
+        }
+        __syncthreads();
+        lds_fft<T, LOG2L, NT, true>(s, tw);
+        // slide: z'[n] = prev pairs (n < L/2), z'[L/2 + n] = new valid pairs; prev <- new
+        constexpr int B = (L / 2 + NT - 1) / NT;
+        c2<T> v[B];
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            const int n = tid + b * NT;
+            if (n < L / 2) v[b] = s[n];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            const int n = tid + b * NT;
+            if (n < L / 2) {
+                s[L / 2 + n] = v[b];
+                s[n] = mk<T>(job.evalprev[2 * n], job.evalprev[2 * n + 1]);
+                job.evalprev[2 * n] = v[b].x;
+                job.evalprev[2 * n + 1] = v[b].y;
+            }
+        }
+        __syncthreads();
+        lds_fft<T, LOG2L, NT, false>(s, tw);
+    }
+
+    for (int k = tid; k <= L / 2; k += NT) {
+        const int k2 = (k == 0 || k == L - k) ? -1 : L - k;
+        c2<T> a = mk<T>((T)0, (T)0), b = mk<T>((T)0, (T)0);
+        bool first = true;
+        for (int i = 0; i < job.n_in; i++) {
+            const c2<T> *sp = in[i].spec + (size_t)(t % (unsigned int)in[i].R) * L;
+            const T sc = in[i].scale;
+            const c2<T> v = sp[k];
+            if (first) a = mk<T>(v.x * sc, v.y * sc); else a = mk<T>(a.x + v.x * sc, a.y + v.y * sc);
+            if (k2 >= 0) {
+                const c2<T> w = sp[k2];
+                if (first) b = mk<T>(w.x * sc, w.y * sc); else b = mk<T>(b.x + w.x * sc, b.y + w.y * sc);
+            }
+            first = false;
+        }
+        if (job.n_up > 0) {
+            c2<T> ek, ek2 = mk<T>((T)0, (T)0);
+            if (k == 0) {
+                ek = mk<T>(s[0].x + s[0].y, s[0].x - s[0].y);
+            } else {
+                const c2<T> za = s[k], zb = conj(s[L - k]);
+                const c2<T> e = mk<T>((T)0.5 * (za.x + zb.x), (T)0.5 * (za.y + zb.y));
+                const c2<T> d = mk<T>((T)0.5 * (za.x - zb.x), (T)0.5 * (za.y - zb.y));
+                const c2<T> wo = cmul(mk<T>(d.y, -d.x), tw[k]);
+                ek = e + wo;
+                ek2 = conj(e - wo);
+            }
+            if (first) { a = ek; b = ek2; } else { a = a + ek; b = b + ek2; }
+        }
+        dst[k] = a;
+        if (k2 >= 0) dst[k2] = b;
+    }
+}
+
+// ------------------------------------------------------------------ per-filter MAC (materialised outputs)
+
+// Y_f[k] = sum_p scale * ring[(t - p - delay) mod R][k] * H[p][k]   (or the dirac spectrum)
+// for filters whose output spectrum must exist on its own: cascade sources (from_filters of
+// another filter) and filters in a cross-fade block (old and new coefficient results).
+template <typename T> struct FilterJob {
+    const c2<T> *ring;
+    const c2<T> *H;
+    c2<T> *Y;
+    T scale;
+    int R, delay, P, kind;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void
+mac_filter_kernel(const FilterJob<T> *__restrict__ jobs, int L, unsigned int t, int age) {
+    constexpr int V = 16 / sizeof(c2<T>);
+    const FilterJob<T> job = jobs[blockIdx.y];
+    const int k0 = ((int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x) * V;
+    if (k0 >= L) return;
+    T acc[2 * V];
+#pragma unroll
+    for (int v = 0; v < 2 * V; v++) acc[v] = (T)0;
+    int P = job.P;
+    if (P > age - job.delay) P = age - job.delay;
+    for (int p = 0; p < P; p++) {
+        const unsigned int slot = (t - (unsigned int)p - (unsigned int)job.delay) % (unsigned int)job.R;
+        const c2<T> *xp = job.ring + (size_t)slot * L + k0;
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+            const int k = k0 + v;
+            const c2<T> x = mk<T>(xp[v].x * job.scale, xp[v].y * job.scale);
+            c2<T> h;
+            if (job.kind == TERM_COEFF) h = job.H[(size_t)p * L + k];
+            else { const T f = (T)1.0 / (T)(2 * L); h = mk<T>((k & 1) ? -f : f, (T)0); if (k == 0) h.y = f; }
+            if (k == 0) { acc[0] += x.x * h.x; acc[1] += x.y * h.y; }
+            else { acc[2 * v] += x.x * h.x - x.y * h.y; acc[2 * v + 1] += x.x * h.y + x.y * h.x; }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < V; v++) job.Y[k0 + v] = mk<T>(acc[2 * v], acc[2 * v + 1]);
+}
+
+// ------------------------------------------------------------------ K6: crossfade
+
+// convolver_crossfade_inplace (fftw_convolver.c:330-368): both results to the time domain, linear
+// ramp over the first L samples (the float branch's arithmetic, used for both precisions: the
+// reference's double branch reads out of bounds), back to the frequency domain, / n_fft.
+template <typename T> struct FadeJob { c2<T> *Ynew; const c2<T> *Yold; };
+
+template <typename T, int LOG2L>
+__device__ __forceinline__ void load_c2r(c2<T> *s, const c2<T> *__restrict__ z,
+                                         const c2<T> *__restrict__ tw) {
+    constexpr int L = 1 << LOG2L, NT = fft_threads(LOG2L);
+    for (int k = threadIdx.x; k <= L / 2; k += NT) {
+        const c2<T> a = z[k];
+        if (k == 0) {
+            s[0] = mk<T>(a.x + a.y, a.x - a.y);
+        } else {
+            const c2<T> b = conj(z[L - k]);
+            const c2<T> e = a + b, d = a - b;
+            const c2<T> o = cmul(d, conj(tw[k]));
+            s[k] = mk<T>(e.x - o.y, e.y + o.x);
+            if (k != L - k) s[L - k] = mk<T>(e.x + o.y, -e.y + o.x);
+        }
+    }
+}
+
+template <typename T, int LOG2L>
+__global__ __launch_bounds__(fft_threads(LOG2L)) void
+crossfade_kernel(const FadeJob<T> *__restrict__ jobs, const c2<T> *__restrict__ tw) {
+    constexpr int L = 1 << LOG2L, NT = fft_threads(LOG2L);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    c2<T> *s = reinterpret_cast<c2<T> *>(smem);
+    const int tid = threadIdx.x;
+    const FadeJob<T> job = jobs[blockIdx.x];
+    constexpr int B = (L / 2 + NT - 1) / NT;
+    c2<T> oldv[B];
+
+    load_c2r<T, LOG2L>(s, job.Yold, tw);
+    __syncthreads();
+    lds_fft<T, LOG2L, NT, true>(s, tw);
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+        const int n = tid + b * NT;
+        if (n < L / 2) oldv[b] = s[n];
+    }
+    __syncthreads();
+    load_c2r<T, LOG2L>(s, job.Ynew, tw);
+    __syncthreads();
+    lds_fft<T, LOG2L, NT, true>(s, tw);
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+        const int n = tid + b * NT;
+        if (n < L / 2) {
+            c2<T> nv = s[n];
+            if constexpr (sizeof(T) == 4) {
+                const float f = 1.0f / (float)(L - 1);
+                const float m0 = (float)(2 * n), m1 = (float)(2 * n + 1);
+                nv.x = (float)((double)oldv[b].x * (1.0 - (double)(f * m0)) + (double)(nv.x * f * m0));
+                nv.y = (float)((double)oldv[b].y * (1.0 - (double)(f * m1)) + (double)(nv.y * f * m1));
+            } else {
+                const double d = 1.0 / (double)(L - 1);
+                const double m0 = (double)(2 * n), m1 = (double)(2 * n + 1);
+                nv.x = oldv[b].x * (1.0 - d * m0) + nv.x * d * m0;
+                nv.y = oldv[b].y * (1.0 - d * m1) + nv.y * d * m1;
+            }
+            s[n] = nv;
+        }
+    }
+    __syncthreads();
+    lds_fft<T, LOG2L, NT, false>(s, tw);
+    const T inv = (T)1.0 / (T)(2 * L);
+    for (int k = tid; k <= L / 2; k += NT) {
+        if (k == 0) {
+            job.Ynew[0] = mk<T>((s[0].x + s[0].y) * inv, (s[0].x - s[0].y) * inv);
+        } else {
+            const c2<T> a = s[k], b = conj(s[L - k]);
+            const c2<T> e = mk<T>((T)0.5 * (a.x + b.x), (T)0.5 * (a.y + b.y));
+            const c2<T> d = mk<T>((T)0.5 * (a.x - b.x), (T)0.5 * (a.y - b.y));
+            const c2<T> wo = cmul(mk<T>(d.y, -d.x), tw[k]);
+            const c2<T> x = e + wo, y = conj(e - wo);
+            job.Ynew[k] = mk<T>(x.x * inv, x.y * inv);
+            if (k != L - k) job.Ynew[L - k] = mk<T>(y.x * inv, y.y * inv);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ K3: spectrum -> raw
 
 // the no-dither requantiser, literally (dither_funs.h:71-114); both precisions go through

@@ -63,3 +63,27 @@ def rel_rms(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.sqrt(((a - b) ** 2).sum() / max((b ** 2).sum(), 1e-300)))
+
+
+# ------------------------------------------------------------------ generic network builder
+
+def build(engine_cls, spec, **kw):
+    """spec: dict(L, N, rs, n_in, n_out, infmt, outfmt, coeffs=[(taps, scale, n_blocks)],
+    filters=[dict(in_ch, in_scale, in_f, in_fscale, out_ch, out_scale, coeff, delayblocks,
+    crossfade)], safety_limit) -> engine (oracle or HIP: same calls)"""
+    e = engine_cls(spec["L"], spec["N"], spec["rs"], spec["n_in"], spec["n_out"], **kw)
+    e.set_interleaved(0, spec["infmt"])
+    e.set_interleaved(1, spec["outfmt"])
+    if spec.get("safety_limit"):
+        e.set_safety_limit(spec["safety_limit"])
+    for taps, scale, nb in spec.get("coeffs", []):
+        e.add_coeff(taps, scale, nb)
+    for f in spec["filters"]:
+        e.add_filter(**f)
+    if hasattr(e, "finalize"):
+        e.finalize()
+    return e
+
+
+def samples(raw, fmt):
+    return np.frombuffer(raw.tobytes(), RAW_NP[fmt]).astype(np.float64)

@@ -1,0 +1,250 @@
+"""GPU parity for every bookkeeping rule and filter-network feature of the path
+(SURVEY A.5 / A.9): HIP engine through the C ABI vs the CPU oracle, same seeded inputs.
+Tolerances: f32 1e-5, f64 1e-12 relative RMS on float outputs; integer outputs within 1 LSB;
+overflow counters equal."""
+import numpy as np
+import pytest
+
+import bforacle as bo
+import cases
+
+pytestmark = pytest.mark.gpu
+TOL = {4: 1e-5, 8: 1e-12}
+FLOATFMT = {4: "FLOAT_LE", 8: "FLOAT64_LE"}
+
+
+def _ir(seed, taps, n_in=1):
+    return cases.make_ir(np.random.default_rng(seed), taps, n_in)
+
+
+def _compare(hip, spec, n_blocks, seed=1, control=None, tol=None):
+    ge = cases.build(hip.Engine, spec)
+    oe = cases.build(bo.Engine, spec)
+    blocks = cases.raw_blocks(seed, n_blocks, spec["L"], spec["n_in"], spec["infmt"])
+    worst = 0.0
+    for b, blk in enumerate(blocks):
+        if control:
+            control(b, ge)
+            control(b, oe)
+        gs, g = ge.block(blk)
+        os_, o = oe.block(blk)
+        assert gs == os_, b
+        gsamp, osamp = cases.samples(g, spec["outfmt"]), cases.samples(o, spec["outfmt"])
+        if spec["outfmt"].startswith("FLOAT"):
+            if np.abs(osamp).max() == 0:
+                assert np.abs(gsamp).max() <= 1e-30, b
+            else:
+                err = cases.rel_rms(gsamp, osamp)
+                worst = max(worst, err)
+                assert err <= (tol or TOL[spec["rs"]]), (b, err)
+        else:
+            assert np.abs(gsamp - osamp).max() <= 1.0, b
+    for ch in range(spec["n_out"]):
+        g, o = ge.overflow(ch), oe.overflow(ch)
+        assert g.n_overflows == o.n_overflows and g.max == o.max, ch
+        assert abs(g.intlargest - o.intlargest) <= 1
+    return worst
+
+
+def _spec(L, N, rs, n_in, n_out, filters, coeffs=(), infmt="S24_4LE", outfmt=None, **kw):
+    return dict(L=L, N=N, rs=rs, n_in=n_in, n_out=n_out, infmt=infmt,
+                outfmt=outfmt or FLOATFMT[rs], coeffs=list(coeffs), filters=filters, **kw)
+
+
+@pytest.mark.parametrize("rs", [4, 8])
+def test_crossbar_both_precisions_nonpow2_partitions(hip, rs):
+    """N = 13 (bench4_config: 4096 x 13): `blockcounter % 13` and the warm-up guard"""
+    L, N, I, O = 256, 13, 3, 2
+    coeffs = [(_ir(10 + k, L * N, I), 1.0, 0) for k in range(I * O)]
+    filters = [dict(in_ch=[i], out_ch=[o], coeff=o * I + i) for o in range(O) for i in range(I)]
+    _compare(hip, _spec(L, N, rs, I, O, filters, coeffs), 2 * N + 2)
+
+
+@pytest.mark.parametrize("rs", [4, 8])
+def test_delay_dirac_scales_short_sets_multi_output(hip, rs):
+    """delayblocks (incl. clamp and cblocks truncation), coeff -1, polarity / attenuation
+    scales, `blocks: 2` sets, one filter feeding two outputs, a filter-less output"""
+    L, N = 128, 6
+    coeffs = [(_ir(1, L * N), 1.0, 0), (_ir(2, L * 2), 0.5, 2), (_ir(3, L * N), 1.0, 0)]
+    filters = [
+        dict(in_ch=[0], out_ch=[0, 1], out_scale=[1.0, -0.5], coeff=0, delayblocks=2),
+        dict(in_ch=[1], out_ch=[1], in_scale=[-1.0], coeff=1),
+        dict(in_ch=[1], out_ch=[0], coeff=-1, delayblocks=1),
+        dict(in_ch=[2], out_ch=[2], coeff=2, delayblocks=9),        # clamps to N-1
+        dict(in_ch=[0], out_ch=[2], coeff=0, in_scale=[0.25]),      # same input+output pair again
+        dict(in_ch=[0], out_ch=[2], coeff=2),
+    ]
+    _compare(hip, _spec(L, N, rs, 3, 4, filters, coeffs), 2 * N + 1)
+
+
+@pytest.mark.parametrize("rs", [4, 8])
+def test_multi_input_mix_filters(hip, rs):
+    """bench4-style filters that mix several inputs with their own scales (A3)"""
+    L, N = 128, 4
+    coeffs = [(_ir(5, L * N, 3), 1.0, 0), (_ir(6, L * N, 3), 1.0, 0)]
+    filters = [
+        dict(in_ch=[0, 1, 2], in_scale=[1.0, -0.5, 0.25], out_ch=[0], coeff=0),
+        dict(in_ch=[2, 0], in_scale=[0.7, 0.3], out_ch=[1, 0], out_scale=[1.0, 0.5], coeff=1, delayblocks=1),
+        dict(in_ch=[1], out_ch=[1], coeff=0),
+    ]
+    _compare(hip, _spec(L, N, rs, 3, 2, filters, coeffs), 2 * N + 1)
+
+
+@pytest.mark.parametrize("rs", [4, 8])
+def test_cascaded_filters_bench1_topology(hip, rs):
+    """from_filters / convolve_eval (A8): two input filters feed two output filters, plus a
+    third level and a filter mixing a channel input with a filter input"""
+    L, N = 128, 4
+    coeffs = [(_ir(20 + k, L * N, 2), 1.0, 0) for k in range(5)]
+    filters = [
+        dict(in_ch=[0], coeff=0),                                            # 0
+        dict(in_ch=[1], coeff=1, out_ch=[2]),                                # 1: also to an output
+        dict(in_f=[0, 1], in_fscale=[1.0, 0.5], out_ch=[0], coeff=2),        # 2
+        dict(in_f=[0, 1], in_fscale=[-1.0, 1.0], out_ch=[1], coeff=3),       # 3
+        dict(in_ch=[0], in_scale=[0.5], in_f=[2], out_ch=[2], coeff=4, delayblocks=1),   # 4: level 2
+    ]
+    tol = 3e-5 if rs == 4 else None      # three FFT round trips deep: error accumulates
+    _compare(hip, _spec(L, N, rs, 2, 3, filters, coeffs), 3 * N, tol=tol)
+
+
+@pytest.mark.parametrize("rs", [4, 8])
+def test_coefficient_switch_with_and_without_crossfade(hip, rs):
+    """fctrl.coeff changes at run time (bflogic_cli `cfc`): hard switch, cross-faded switch,
+    switch to and from the dirac (coeff -1), bench5-style toggling every block"""
+    L, N = 128, 4
+    coeffs = [(_ir(30, L * N), 1.0, 0), (_ir(31, L * N), 1.0, 0), (_ir(32, L * 2), 1.0, 2)]
+    filters = [
+        dict(in_ch=[0], out_ch=[0], coeff=0, crossfade=True),
+        dict(in_ch=[1], out_ch=[1], coeff=1, crossfade=False),
+        dict(in_ch=[0, 1], out_ch=[2], coeff=0, crossfade=True),
+    ]
+    plan = {3: [(0, 1), (1, 0)], 5: [(0, -1), (2, 2)], 6: [(0, 2)], 7: [(0, 0), (2, -1)],
+            8: [(0, 1)], 9: [(0, 0)], 10: [(0, 1)]}
+
+    def control(b, eng):
+        for f, c in plan.get(b, []):
+            eng.set_coeff(f, c)
+    _compare(hip, _spec(L, N, rs, 2, 3, filters, coeffs), 14, control=control)
+
+
+def test_runtime_coefficient_update_like_bflogic_eq(hip):
+    """convolver_runtime_coeffs2cbuf: one partition of a live coefficient set is replaced"""
+    L, N = 256, 4
+    spec = _spec(L, N, 4, 1, 1, [dict(in_ch=[0], out_ch=[0], coeff=0)], [(_ir(40, L * N), 1.0, 0)])
+    ge = cases.build(hip.Engine, spec)
+    taps = _ir(40, L * N).copy()
+    new = _ir(41, L)
+    for b, blk in enumerate(cases.raw_blocks(2, 10, L, 1, "S24_4LE")):
+        if b == 4:
+            ge.update_coeff_block(0, 2, new)
+            taps[2 * L:3 * L] = new
+            oe = cases.build(bo.Engine, dict(spec, coeffs=[(taps, 1.0, 0)]))
+            # replay history into a fresh oracle that has the updated set from the start:
+            # from block 4 + N on the outputs must agree again
+            for old in cases.raw_blocks(2, 4, L, 1, "S24_4LE"):
+                oe.block(old)
+        _, g = ge.block(blk)
+        if b >= 4:
+            _, o = oe.block(blk)
+            if b >= 4 + N:
+                assert cases.rel_rms(cases.samples(g, "FLOAT_LE"), cases.samples(o, "FLOAT_LE")) <= 1e-5
+
+
+ALL_FORMATS = ["S8", "S16_LE", "S16_BE", "S24_LE", "S24_BE", "S24_4LE", "S24_4BE", "S32_LE",
+               "S32_BE", "FLOAT_LE", "FLOAT_BE", "FLOAT64_LE", "FLOAT64_BE"]
+
+
+@pytest.mark.parametrize("fmt", ALL_FORMATS)
+def test_every_sample_format_in_and_out(hip, fmt):
+    """dirac filter: raw -> real -> FFT -> IFFT -> raw for all 13 formats, interleaved 3 ch"""
+    L, N, ch = 64, 2, 3
+    nbytes, sbytes, isfloat, le = bo.SAMPLE_FORMATS[fmt]
+    rng = np.random.default_rng(50)
+    ge = hip.Engine(L, N, 8, ch, ch)
+    oe = bo.Engine(L, N, 8, ch, ch)
+    for e in (ge, oe):
+        e.set_interleaved(0, fmt)
+        e.set_interleaved(1, fmt)
+        for c in range(ch):
+            e.add_filter(in_ch=[c], out_ch=[c], coeff=-1, in_scale=[0.5])
+    ge.finalize()
+    for _ in range(3):
+        if isfloat:
+            vals = (rng.standard_normal(L * ch) * 0.5).astype(np.float32 if nbytes == 4 else np.float64)
+            raw = vals.view(np.uint8).copy()
+            if not le:
+                raw = raw.reshape(-1, nbytes)[:, ::-1].copy().ravel()
+        else:
+            raw = rng.integers(0, 256, L * ch * nbytes, dtype=np.uint8)
+        gs, g = ge.block(raw)
+        os_, o = oe.block(raw)
+        assert gs == os_ == 0
+        if isfloat:
+            gv = g.reshape(-1, nbytes)[:, ::(1 if le else -1)].copy().view(np.float32 if nbytes == 4 else np.float64)
+            ov = o.reshape(-1, nbytes)[:, ::(1 if le else -1)].copy().view(np.float32 if nbytes == 4 else np.float64)
+            assert np.abs(gv - ov).max() <= 1e-6
+        else:
+            # identical up to one LSB of the integer format (f64 path: rounding only)
+            dec = bo.Ctx(64, 8)
+            gi = dec.raw2real(g, nbytes, 0, 1, 0 if le else 1, L * ch)
+            oi = dec.raw2real(o, nbytes, 0, 1, 0 if le else 1, L * ch)
+            assert np.abs(gi - oi).max() <= 1.0
+    for c in range(ch):
+        assert ge.overflow(c).n_overflows == oe.overflow(c).n_overflows
+
+
+def test_clipping_counters_bit_exact(hip):
+    """S16 output driven into clipping: n_overflows / intlargest / largest as the reference's
+    requantiser counts them (dither_funs.h:71-114)"""
+    L = 256
+    spec = _spec(L, 1, 8, 2, 2, [dict(in_ch=[0], out_ch=[0], coeff=-1, out_scale=[3.0]),
+                                  dict(in_ch=[1], out_ch=[1], coeff=-1)],
+                 infmt="FLOAT64_LE", outfmt="S16_LE")
+    ge, oe = cases.build(hip.Engine, spec), cases.build(bo.Engine, spec)
+    rng = np.random.default_rng(3)
+    for _ in range(4):
+        x = rng.standard_normal((L, 2)) * 0.5
+        gs, g = ge.block(x)
+        os_, o = oe.block(x)
+        assert gs == os_ == 0
+        assert np.abs(g.view(np.int16).astype(int) - o.view(np.int16).astype(int)).max() <= 1
+    for ch in range(2):
+        g, o = ge.overflow(ch), oe.overflow(ch)
+        assert o.n_overflows > 0 if ch == 0 else True
+        assert g.n_overflows == o.n_overflows
+        assert g.intlargest == o.intlargest
+        assert g.largest == pytest.approx(o.largest, rel=1e-12)
+    ge.reset_overflow()
+    assert ge.overflow(0).astuple() == (0, 0, 0.0, 32767.0)
+
+
+def test_nan_and_safety_limit_status(hip):
+    L = 64
+    spec = _spec(L, 1, 4, 1, 1, [dict(in_ch=[0], out_ch=[0], coeff=-1)], infmt="FLOAT_LE",
+                 safety_limit=2.0)
+    ge, oe = cases.build(hip.Engine, spec), cases.build(bo.Engine, spec)
+    x = np.zeros((L, 1), np.float32)
+    assert ge.block(x)[0] == oe.block(x)[0] == 0
+    x[5] = 3.0
+    assert ge.block(x)[0] == oe.block(x)[0] == hip.ST_SAFETY
+    x[5] = np.nan
+    assert ge.block(x)[0] & hip.ST_NONFINITE and oe.block(x)[0] == 1
+    x[5] = 0.0
+    # status is per block: the engine keeps running afterwards (the host decides to exit)
+    ge.block(x)
+
+
+def test_bad_configuration_is_rejected(hip):
+    with pytest.raises(hip.BfhipError, match="Invalid length"):
+        hip.Engine(100, 4, 4, 1, 1)
+    e = hip.Engine(64, 2, 4, 1, 1)
+    with pytest.raises(hip.BfhipError, match="NaN or Inf"):
+        e.add_coeff(np.array([1.0, np.inf]))
+    with pytest.raises(hip.BfhipError):
+        e.add_coeff(np.zeros(64 * 3), n_blocks=3)       # more blocks than the engine has
+    with pytest.raises(hip.BfhipError):
+        e.add_filter(in_ch=[0], out_ch=[0], coeff=7)    # coefficient set not loaded
+    with pytest.raises(hip.BfhipError):
+        e.add_filter(in_f=[3], out_ch=[0])              # from_filter not defined yet
+    with pytest.raises(hip.BfhipError):
+        e.block(np.zeros(64, np.float32))               # not finalized
