@@ -120,6 +120,17 @@ struct bfhip_engine {
     size_t src_off = 0;
     bool any_fading = false;
 
+    // HP-TPDF dither (dither.c, dither.h)
+    std::vector<int> dither_channels;      // output channel of each dither slot
+    std::vector<int8_t> dither_table;
+    int dither_spacing = 0;
+    int *d_dither_ch = nullptr;
+    void *d_dither_state = nullptr;
+    int8_t *d_dither_table = nullptr;
+    void *d_randmap = nullptr;             // 512 entries; centre at +256
+    unsigned char *d_skip_quant = nullptr; // [n_out] 1 = the dither pass writes this channel
+    void *d_timeout = nullptr;             // [n_out][L] time samples for the dither pass
+
     // plan geometry
     int n_groups = 0, n_out_padded = 0, n_chunks = 1, n_tiles = 1, mac_threads = 256;
     int n_entries = 0;
@@ -195,9 +206,25 @@ void launch_ifft_out(bfhip_engine *e, const void *Zp, size_t chunk_stride, int n
     *err = allow_lds(k, lds);
     if (*err != hipSuccess) return;
     hipLaunchKernelGGL(k, dim3(count), dim3(NT), lds, e->stream, (const c2<T> *)Zp, chunk_stride,
-                       n_chunks, first, e->d_fmt[1], e->d_over, (const unsigned char *)nullptr,
-                       raw, (T *)nullptr, (const c2<T> *)e->d_tw, e->safety_limit, e->d_status);
+                       n_chunks, first, e->d_fmt[1], e->d_over, (const unsigned char *)e->d_skip_quant,
+                       raw, e->d_timeout ? (T *)e->d_timeout + (size_t)first * e->L : (T *)nullptr,
+                       (const c2<T> *)e->d_tw, e->safety_limit, e->d_status);
     *err = hipGetLastError();
+    if (*err != hipSuccess || e->dither_channels.empty()) return;
+    // dither slots whose channel lies in [first, first+count): the slots are sorted by channel
+    int s0 = 0, s1 = 0;
+    for (size_t i = 0; i < e->dither_channels.size(); i++) {
+        if (e->dither_channels[i] < first) s0 = (int)i + 1;
+        if (e->dither_channels[i] < first + count) s1 = (int)i + 1;
+    }
+    if (s1 > s0) {
+        hipLaunchKernelGGL(dither_kernel<T>, dim3(s1 - s0), dim3(64), 0, e->stream,
+                           (const T *)e->d_timeout, (const int *)e->d_dither_ch + s0,
+                           (DitherState<T> *)e->d_dither_state + s0, (const int8_t *)e->d_dither_table,
+                           (int)e->dither_table.size(), (const T *)e->d_randmap + 256,
+                           e->d_fmt[1], e->d_over, raw, e->L, e->safety_limit, e->d_status);
+        *err = hipGetLastError();
+    }
 }
 
 template <typename T>
@@ -664,7 +691,8 @@ void bfhip_engine_destroy(bfhip_engine *e) {
     for (auto &c : e->coeffs) if (c.d_H) (void)hipFree(c.d_H);
     void *ptrs[] = {e->d_tw, e->d_prev, e->d_ring, e->d_fmt[0], e->d_fmt[1], e->d_over, e->d_status,
                     e->d_bad, e->d_Zp, e->d_entries, e->d_chunks, e->d_rawin, e->d_rawout, e->d_taps,
-                    e->d_fring, e->d_Y, e->d_Yold, e->d_evalprev, e->d_jobs};
+                    e->d_fring, e->d_Y, e->d_Yold, e->d_evalprev, e->d_jobs,
+                    e->d_dither_ch, e->d_dither_state, e->d_dither_table, e->d_randmap, e->d_skip_quant, e->d_timeout};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto ev : e->ev) (void)hipEventDestroy(ev);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -685,9 +713,75 @@ int bfhip_engine_set_safety_limit(bfhip_engine *e, double limit) {
     return BFHIP_OK;
 }
 
-int bfhip_engine_enable_dither(bfhip_engine *e, const int[], int, int, int) {
-    (void)e;
-    return fail(BFHIP_EINVAL, "dither is not available in this build of the device path");
+int bfhip_engine_enable_dither(bfhip_engine *e, const int out_channels[], int n,
+                               int sample_rate, int max_size) {
+    if (!e || !out_channels || n < 1 || sample_rate < 1) return fail(BFHIP_EINVAL, "enable_dither: bad argument");
+    if (e->finalized) return fail(BFHIP_ESTATE, "enable_dither after finalize");
+    std::vector<int> chs(out_channels, out_channels + n);
+    for (int i = 0; i < n; i++) {
+        if (chs[i] < 0 || chs[i] >= e->n_ch[1]) return fail(BFHIP_EINVAL, "enable_dither: output channel %d", chs[i]);
+        if (i > 0 && chs[i] <= chs[i - 1]) return fail(BFHIP_EINVAL, "enable_dither: channels must be ascending");
+        if (e->fmt[1][chs[i]].isfloat) return fail(BFHIP_EINVAL, "cannot dither floating point format (output %d)", chs[i]);
+    }
+    // dither_init (dither.c:75-139): table spacing, Tausworthe bytes
+    int spacing = 10 * sample_rate;
+    const int minspacing = sample_rate > e->L ? sample_rate : e->L;
+    if (spacing < minspacing) spacing = minspacing;
+    if (max_size > 0 && n * spacing > max_size) spacing = max_size / n;
+    if (spacing < minspacing)
+        return fail(BFHIP_EINVAL, "Maximum dither table size %d bytes is too small, must at least be %d bytes.",
+                    max_size, n * sample_rate * minspacing);
+    e->dither_spacing = spacing;
+    e->dither_table.resize((size_t)n * spacing + 1);
+    uint32_t st[3];
+    auto lcg = [](uint32_t v) { return (uint32_t)(69069u * v); };
+    st[0] = lcg(1); st[1] = lcg(st[0]); st[2] = lcg(st[1]);
+    auto taus = [&]() {
+        st[0] = ((st[0] & 4294967294u) << 12) ^ (((st[0] << 13) ^ st[0]) >> 19);
+        st[1] = ((st[1] & 4294967288u) << 4) ^ (((st[1] << 2) ^ st[1]) >> 25);
+        st[2] = ((st[2] & 4294967280u) << 17) ^ (((st[2] << 3) ^ st[2]) >> 11);
+        return st[0] ^ st[1] ^ st[2];
+    };
+    for (int i = 0; i < 6; i++) taus();
+    for (auto &b : e->dither_table) b = (int8_t)(taus() & 0xFF);
+    e->dither_channels = chs;
+    return BFHIP_OK;
+}
+
+static int dither_upload(bfhip_engine *e) {
+    const int n = (int)e->dither_channels.size();
+    if (n == 0) return BFHIP_OK;
+    HIPCHK(hipMalloc((void **)&e->d_dither_ch, n * sizeof(int)));
+    HIPCHK(hipMemcpy(e->d_dither_ch, e->dither_channels.data(), n * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **)&e->d_dither_table, e->dither_table.size()));
+    HIPCHK(hipMemcpy(e->d_dither_table, e->dither_table.data(), e->dither_table.size(), hipMemcpyHostToDevice));
+    // randmap[d] = 0.5 + (d + 1)/255 for d in -255..253, [-256] = -0.5, [254] = 1.5
+    // (dither.c:115-131).  The reference indexes it with int8 - int8, which can be +255: one
+    // element past its table (undefined there); defined here by continuing the formula.
+    std::vector<unsigned char> map(512 * e->rs);
+    for (int d = -256; d < 256; d++) {
+        if (e->rs == 4) {
+            float v = d == -256 ? -0.5f : (d == 254 ? 1.5f : (float)(0.5 + 1.0 / 255.0 + 1.0 / 255.0 * (float)d));
+            ((float *)map.data())[d + 256] = v;
+        } else {
+            double v = d == -256 ? -0.5 : (d == 254 ? 1.5 : 0.5 + 1.0 / 255.0 + 1.0 / 255.0 * (double)d);
+            ((double *)map.data())[d + 256] = v;
+        }
+    }
+    HIPCHK(hipMalloc(&e->d_randmap, map.size()));
+    HIPCHK(hipMemcpy(e->d_randmap, map.data(), map.size(), hipMemcpyHostToDevice));
+    // per-slot state: ptr = n*spacing + 1, error feedback zero (dither.c:133-137)
+    const size_t ssz = e->rs == 4 ? sizeof(DitherState<float>) : sizeof(DitherState<double>);
+    std::vector<unsigned char> stv(ssz * n, 0);
+    for (int i = 0; i < n; i++) *(int *)(stv.data() + ssz * i) = i * e->dither_spacing + 1;
+    HIPCHK(hipMalloc(&e->d_dither_state, stv.size()));
+    HIPCHK(hipMemcpy(e->d_dither_state, stv.data(), stv.size(), hipMemcpyHostToDevice));
+    std::vector<unsigned char> skip(e->n_ch[1], 0);
+    for (int c : e->dither_channels) skip[c] = 1;
+    HIPCHK(hipMalloc((void **)&e->d_skip_quant, skip.size()));
+    HIPCHK(hipMemcpy(e->d_skip_quant, skip.data(), skip.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&e->d_timeout, (size_t)e->n_ch[1] * e->L * e->rs));
+    return BFHIP_OK;
 }
 
 static int add_coeff_common(bfhip_engine *e, const void *taps, bool on_device, int n_taps,
@@ -840,6 +934,7 @@ int bfhip_engine_finalize(bfhip_engine *e) {
         if ((r = zalloc(&e->d_Yold, (size_t)e->n_fadeable * L * e->csize())) != BFHIP_OK) return r;
         if ((r = zalloc(&e->d_evalprev, (size_t)e->n_sinks * L * e->rs)) != BFHIP_OK) return r;
     }
+    if ((r = dither_upload(e)) != BFHIP_OK) return r;
     e->finalized = true;
     r = bfhip_engine_reset_overflow(e);
     if (r != BFHIP_OK) return r;

@@ -713,4 +713,96 @@ ifft_out_kernel(const c2<T> *__restrict__ Zp, size_t chunk_stride, int n_chunks,
     }
 }
 
+// ------------------------------------------------------------------ K3d: HP-TPDF dithered requantiser
+
+// dither_funs.h:7-69 + dither.h:28-38.  The error feedback {1,-1} makes sample n depend on
+// the quantised sample n-1, so one channel is one sequential chain: one wave per dithered
+// channel, lane 0 walks the block, the wave stages samples and table bytes through LDS in
+// coalesced chunks.  The reference wraps its table walk by copying the last used byte to
+// table[0]; only the wrapping channel ever reads that byte again (as the predecessor of its
+// first sample), so the device keeps the table immutable and carries the byte in a register.
+template <typename T> struct DitherState { int ptr; int pad; T s0, s1; };
+
+template <typename T>
+__global__ __launch_bounds__(64) void
+dither_kernel(const T *__restrict__ samples,          // [n_out][L] from ifft_out_kernel
+              const int *__restrict__ channels,       // output channel of each dither slot
+              DitherState<T> *__restrict__ state, const int8_t *__restrict__ table, int table_size,
+              const T *__restrict__ randmap,          // index -256..255 (centre pointer)
+              const DevFormat *__restrict__ fmt, DevOverflow *__restrict__ over,
+              uint8_t *__restrict__ raw, int L, double safety_limit, int *__restrict__ status) {
+    constexpr int CH = 512;
+    __shared__ T xs[CH];
+    __shared__ int8_t rs[CH + 1];
+    const int slot = blockIdx.x, lane = threadIdx.x;
+    const int ch = channels[slot];
+    const DevFormat f = fmt[ch];
+    const T *x = samples + (size_t)ch * L;
+    uint8_t *base = raw + f.byte_offset;
+    const size_t stride = (size_t)f.sample_spacing * f.bytes;
+    const int bits = f.sbytes << 3;
+    const int32_t imin = (int32_t)(-((uint64_t)1 << (bits - 1)));
+    const int32_t imax = (int32_t)(((uint64_t)1 << (bits - 1)) - 1);
+    const T rmin = (T)imin, rmax = (T)imax;
+
+    DitherState<T> st = state[slot];
+    DevOverflow of = over[ch];
+    int ptr = st.ptr;
+    const int8_t pred = table[ptr - 1];
+    if (ptr + L >= table_size) ptr = 1;                 // dither_preloop_real2int_hp_tpdf
+    const int8_t *tab = table + ptr;
+    int8_t prev_r = pred;
+    int flags = 0;
+
+    for (int c0 = 0; c0 < L; c0 += CH) {
+        const int cn = min(CH, L - c0);
+        __syncthreads();
+        for (int i = lane; i < cn; i += 64) { xs[i] = x[c0 + i]; rs[i] = tab[c0 + i]; }
+        __syncthreads();
+        if (lane == 0) {
+            for (int i = 0; i < cn; i++) {
+                T v = xs[i];
+                const int8_t r = rs[i];
+                uint8_t *p = base + (size_t)(c0 + i) * stride;
+                if (!isfinite(v)) { flags |= 1; prev_r = r; continue; }
+                if (safety_limit != 0.0 && ((double)v < -safety_limit * of.max || (double)v > safety_limit * of.max)) {
+                    flags |= 2; prev_r = r; continue;
+                }
+                v += st.s0 - st.s1;
+                st.s1 = st.s0;
+                const T dv = v + randmap[(int)r - (int)prev_r];
+                prev_r = r;
+                int32_t q;
+                if (dv < 0) {
+                    if (dv <= rmin) {
+                        q = imin; of.n_overflows++;
+                        if ((double)v < -of.largest) of.largest = (double)-dv;
+                    } else {
+                        q = (int32_t)dv; q--;
+                        if (q < -of.intlargest) of.intlargest = -q;
+                    }
+                } else {
+                    if (dv > rmax) {
+                        q = imax; of.n_overflows++;
+                        if ((double)v > of.largest) of.largest = (double)dv;
+                    } else {
+                        q = (int32_t)dv;
+                        if (q > of.intlargest) of.intlargest = q;
+                    }
+                }
+                st.s0 = v - (T)q;
+                const uint32_t u = (uint32_t)q;
+                uint8_t tb[4] = {(uint8_t)(u & 0xff), (uint8_t)((u >> 8) & 0xff), (uint8_t)((u >> 16) & 0xff), (uint8_t)(u >> 24)};
+                store_raw_bytes(p, tb, f.bytes, f.swap);
+            }
+        }
+    }
+    if (lane == 0) {
+        st.ptr = ptr + L;
+        state[slot] = st;
+        over[ch] = of;
+        if (flags) atomicOr(status, flags);
+    }
+}
+
 }  // namespace bfhip

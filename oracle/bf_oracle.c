@@ -276,17 +276,19 @@ bfo_dither_init(bfo_ctx *c, int n_channels, int sample_rate, int max_size,
     for (n = 0; n < 6; n++) taus_next(s);
     for (n = 0; n < c->randtab_size; n++) c->randtab[n] = (int8_t)(taus_next(s) & 0xFF);
 
-    c->randmap_base = malloc(511 * c->rs);
+    /* 511 entries in the reference, indexed with int8 - int8 which can be +255: one past
+       the table (undefined there).  Entry 255 is defined here by continuing the formula. */
+    c->randmap_base = malloc(512 * c->rs);
     c->randmap = (uint8_t *)c->randmap_base + 256 * c->rs;
     if (c->rs == 4) {
         float *m = c->randmap;
         m[-256] = -0.5;
-        for (n = -255; n < 254; n++) m[n] = 0.5 + 1.0 / 255.0 + 1.0 / 255.0 * (float)n;
+        for (n = -255; n < 256; n++) m[n] = 0.5 + 1.0 / 255.0 + 1.0 / 255.0 * (float)n;
         m[254] = 1.5;
     } else {
         double *m = c->randmap;
         m[-256] = -0.5;
-        for (n = -255; n < 254; n++) m[n] = 0.5 + 1.0 / 255.0 + 1.0 / 255.0 * (double)n;
+        for (n = -255; n < 256; n++) m[n] = 0.5 + 1.0 / 255.0 + 1.0 / 255.0 * (double)n;
         m[254] = 1.5;
     }
     c->n_dstates = n_channels;

@@ -248,3 +248,65 @@ def test_bad_configuration_is_rejected(hip):
         e.add_filter(in_f=[3], out_ch=[0])              # from_filter not defined yet
     with pytest.raises(hip.BfhipError):
         e.block(np.zeros(64, np.float32))               # not finalized
+
+
+def test_hp_tpdf_dither_bit_exact_f64(hip):
+    """HP-TPDF dither to S16 (dither_funs.h:7-69): integer-valued samples through a dirac filter
+    in f64 reach the requantiser exact to 1e-12, far from every rounding boundary (those sit at
+    odd multiples of 1/510), so the device must reproduce the oracle -- which matches the
+    reference's code bit for bit (tests/test_oracle_golden.py) -- exactly: samples, error
+    feedback across blocks, table walk incl. a wrap, overflow struct."""
+    L, N, ch = 256, 2, 3
+    spec = _spec(L, N, 8, ch, ch,
+                 [dict(in_ch=[c], out_ch=[c], coeff=-1, out_scale=[1.0 / 32768.0]) for c in range(ch)],
+                 infmt="FLOAT64_LE", outfmt="S16_LE")
+
+    def mk(cls):
+        e = cls(L, N, 8, ch, ch)
+        e.set_interleaved(0, "FLOAT64_LE")
+        e.set_interleaved(1, "S16_LE")
+        e.enable_dither([0, 2], 300)         # table 2*3000+1 bytes: wraps after ~11 blocks
+        for f in spec["filters"]:
+            e.add_filter(**f)
+        if hasattr(e, "finalize"):
+            e.finalize()
+        return e
+    ge, oe = mk(hip.Engine), mk(bo.Engine)
+    rng = np.random.default_rng(77)
+    for b in range(30):
+        x = np.round(rng.standard_normal((L, ch)) * 9000.0)
+        x[5, 0] = 40000.0
+        x[9, 2] = -50000.0
+        gs, g = ge.block(x)
+        os_, o = oe.block(x)
+        assert gs == os_ == 0
+        assert np.array_equal(g.view(np.int16), o.view(np.int16)), b
+    for c in range(ch):
+        g, o = ge.overflow(c), oe.overflow(c)
+        assert (g.n_overflows, g.intlargest, g.max) == (o.n_overflows, o.intlargest, o.max), c
+        assert g.largest == pytest.approx(o.largest, rel=1e-12)     # a float: FFT rounding
+
+
+def test_hp_tpdf_dither_f32_within_one_lsb(hip):
+    L, N, ch = 1024, 4, 2
+    coeffs = [(_ir(60 + c, L * N), 1.0, 0) for c in range(ch)]
+
+    def mk(cls):
+        e = cls(L, N, 4, ch, ch)
+        e.set_interleaved(0, "S24_4LE")
+        e.set_interleaved(1, "S16_LE")
+        e.enable_dither([0, 1], 44100)
+        for t, s, nb in coeffs:
+            e.add_coeff(t, s, nb)
+        for c in range(ch):
+            e.add_filter(in_ch=[c], out_ch=[c], coeff=c)
+        if hasattr(e, "finalize"):
+            e.finalize()
+        return e
+    ge, oe = mk(hip.Engine), mk(bo.Engine)
+    for blk in cases.raw_blocks(9, 8, L, ch, "S24_4LE", amplitude=0.3):
+        gs, g = ge.block(blk)
+        os_, o = oe.block(blk)
+        assert gs == os_ == 0
+        d = np.abs(g.view(np.int16).astype(int) - o.view(np.int16).astype(int))
+        assert d.max() <= 2 and (d > 0).mean() < 0.05
