@@ -16,6 +16,14 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def hip():
     """The product library.  GPU tests fail loudly (never skip) if it cannot run."""
+    # torch bundles its own copy of the HIP runtime: when a test also needs torch (device
+    # tensors for the full-size cases) it has to be initialised before libbfhip.so pulls in
+    # /opt/rocm's copy, the order bench.py uses
+    try:
+        import torch
+        torch.cuda.is_available()
+    except Exception:
+        pass
     import brutefir_amd as bf
     bf.lib()
     assert bf.device_count() >= 1, "no HIP device visible"
