@@ -105,6 +105,7 @@ def lib():
     L.bfhip_engine_reset_overflow.argtypes = [vp]
     L.bfhip_engine_blockcounter.restype = C.c_uint
     L.bfhip_engine_blockcounter.argtypes = [vp]
+    L.bfhip_engine_ring_depth.argtypes = [vp]
     L.bfhip_engine_enable_timing.argtypes = [vp, ci]
     L.bfhip_engine_get_timing.argtypes = [vp, dp]
     L.bfhip_engine_algorithmic_bytes.argtypes = [vp, dp]
@@ -262,6 +263,10 @@ class Engine:
     @property
     def blockcounter(self):
         return lib().bfhip_engine_blockcounter(self.h)
+
+    @property
+    def ring_depth(self):
+        return lib().bfhip_engine_ring_depth(self.h)
 
     # ---- measurement / debug
     def enable_timing(self, on=True):

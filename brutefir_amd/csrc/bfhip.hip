@@ -82,8 +82,18 @@ struct bfhip_engine {
     unsigned int blockcounter = 0;
     unsigned long long blocks_done = 0;      // since creation (procblocks analogue)
 
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // main stream: per-filter kernels and the crossbar MAC
     bool own_stream = false;
+    hipStream_t ls = nullptr;          // stream the next launch goes to
+    // Pipelined block (bfhip_engine_block[_dev]): the input FFT of block t+1 and the inverse
+    // FFT / requantiser of block t-1 run on their own streams beside the HBM-bound MAC of
+    // block t, the way the reference overlaps its input, filter and output processes
+    // (bfrun.c:2312-2616).  Needs one spare ring slot (R = N + 1) and two Zp buffers.
+    bool pipelined = false;            // opt-in (BFHIP_OVERLAP=1): measured slower on MI355X, see DESIGN.md
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_mac[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+    int R = 0;                         // depth of the input rings
+    void *d_Zp2 = nullptr;             // second partial-spectra buffer
 
     // device state
     void *d_tw = nullptr;          // [2L] complex
@@ -134,17 +144,25 @@ struct bfhip_engine {
     // plan geometry
     int n_groups = 0, n_out_padded = 0, n_chunks = 1, n_tiles = 1, mac_threads = 256;
     int n_entries = 0;
+    bool mac_nt = true;            // non-temporal coefficient loads (BFHIP_MAC_NT=0 turns them off)
     double alg_bytes_total = 0, alg_bytes_mac = 0;
 
     // timing
     bool timing = false;
-    std::vector<hipEvent_t> ev;    // 4 per block: before K1, after K1, after K2, after K3
+    std::vector<hipEvent_t> ev;    // 6 per block: start/stop of K1, K2, K3 on their streams
     int ev_used = 0;
 
     size_t csize() const { return (size_t)2 * rs; }     // bytes per complex
 };
 
 namespace {
+
+int sync_all(bfhip_engine *e) {
+    if (e->s_in) HIPCHK(hipStreamSynchronize(e->s_in));
+    if (e->stream) HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->s_out) HIPCHK(hipStreamSynchronize(e->s_out));
+    return BFHIP_OK;
+}
 
 // ---------------------------------------------------------------- template dispatch
 
@@ -179,8 +197,8 @@ void launch_fft_in(bfhip_engine *e, const uint8_t *raw, int slot, hipError_t *er
     auto k = fft_in_kernel<T, LOG2L>;
     *err = allow_lds(k, lds);
     if (*err != hipSuccess) return;
-    hipLaunchKernelGGL(k, dim3(e->n_ch[0]), dim3(NT), lds, e->stream, raw, e->d_fmt[0],
-                       (T *)e->d_prev, (c2<T> *)e->d_ring, (const c2<T> *)e->d_tw, e->N, slot);
+    hipLaunchKernelGGL(k, dim3(e->n_ch[0]), dim3(NT), lds, e->ls, raw, e->d_fmt[0],
+                       (T *)e->d_prev, (c2<T> *)e->d_ring, (const c2<T> *)e->d_tw, e->R, slot);
     *err = hipGetLastError();
 }
 
@@ -205,7 +223,7 @@ void launch_ifft_out(bfhip_engine *e, const void *Zp, size_t chunk_stride, int n
     auto k = ifft_out_kernel<T, LOG2L>;
     *err = allow_lds(k, lds);
     if (*err != hipSuccess) return;
-    hipLaunchKernelGGL(k, dim3(count), dim3(NT), lds, e->stream, (const c2<T> *)Zp, chunk_stride,
+    hipLaunchKernelGGL(k, dim3(count), dim3(NT), lds, e->ls, (const c2<T> *)Zp, chunk_stride,
                        n_chunks, first, e->d_fmt[1], e->d_over, (const unsigned char *)e->d_skip_quant,
                        raw, e->d_timeout ? (T *)e->d_timeout + (size_t)first * e->L : (T *)nullptr,
                        (const c2<T> *)e->d_tw, e->safety_limit, e->d_status);
@@ -218,7 +236,7 @@ void launch_ifft_out(bfhip_engine *e, const void *Zp, size_t chunk_stride, int n
         if (e->dither_channels[i] < first + count) s1 = (int)i + 1;
     }
     if (s1 > s0) {
-        hipLaunchKernelGGL(dither_kernel<T>, dim3(s1 - s0), dim3(64), 0, e->stream,
+        hipLaunchKernelGGL(dither_kernel<T>, dim3(s1 - s0), dim3(64), 0, e->ls,
                            (const T *)e->d_timeout, (const int *)e->d_dither_ch + s0,
                            (DitherState<T> *)e->d_dither_state + s0, (const int8_t *)e->d_dither_table,
                            (int)e->dither_table.size(), (const T *)e->d_randmap + 256,
@@ -233,10 +251,16 @@ void launch_mac(bfhip_engine *e, void *Zp, hipError_t *err) {
     const int tc8 = (n_tc + 7) / 8;
     const int grid = tc8 * e->n_groups * 8;
     const unsigned long long age64 = std::min<unsigned long long>(e->blocks_done + 1, (unsigned long long)e->N);
-    hipLaunchKernelGGL(mac_xbar_kernel<T>, dim3(grid), dim3(e->mac_threads), 0, e->stream,
-                       (const MacEntry<T> *)e->d_entries, (const ChunkRange *)e->d_chunks,
-                       (c2<T> *)Zp, e->L, e->n_out_padded, e->n_groups, e->n_chunks, n_tc,
-                       e->blockcounter, (int)age64);
+    if (e->mac_nt)
+        hipLaunchKernelGGL((mac_xbar_kernel<T, true>), dim3(grid), dim3(e->mac_threads), 0, e->ls,
+                           (const MacEntry<T> *)e->d_entries, (const ChunkRange *)e->d_chunks,
+                           (c2<T> *)Zp, e->L, e->n_out_padded, e->n_groups, e->n_chunks, n_tc,
+                           e->blockcounter, (int)age64);
+    else
+        hipLaunchKernelGGL((mac_xbar_kernel<T, false>), dim3(grid), dim3(e->mac_threads), 0, e->ls,
+                           (const MacEntry<T> *)e->d_entries, (const ChunkRange *)e->d_chunks,
+                           (c2<T> *)Zp, e->L, e->n_out_padded, e->n_groups, e->n_chunks, n_tc,
+                           e->blockcounter, (int)age64);
     *err = hipGetLastError();
 }
 
@@ -245,7 +269,7 @@ void launch_sum(bfhip_engine *e, const void *Zp, void *Z, hipError_t *err) {
     const size_t n_per_chunk = (size_t)e->n_out_padded * e->L;
     const size_t n_valid = (size_t)e->n_ch[1] * e->L;
     const int grid = (int)((n_valid + 255) / 256);
-    hipLaunchKernelGGL(sum_partials_kernel<T>, dim3(grid), dim3(256), 0, e->stream,
+    hipLaunchKernelGGL(sum_partials_kernel<T>, dim3(grid), dim3(256), 0, e->ls,
                        (const c2<T> *)Zp, (c2<T> *)Z, n_per_chunk, n_valid, e->n_chunks);
     *err = hipGetLastError();
 }
@@ -264,18 +288,18 @@ void launch_levels(bfhip_engine *e, hipError_t *err) {
     for (auto &lj : e->level_jobs) {
         if (lj.n_fill > 0) {
             if ((*err = allow_lds(kf, lds)) != hipSuccess) return;
-            hipLaunchKernelGGL(kf, dim3(lj.n_fill), dim3(NT), lds, e->stream,
+            hipLaunchKernelGGL(kf, dim3(lj.n_fill), dim3(NT), lds, e->ls,
                                (const FillJob<T> *)(base + lj.fill_off),
                                (const MixSrc<T> *)(base + e->src_off), (const c2<T> *)e->d_tw,
                                e->N, e->blockcounter);
         }
         if (lj.n_filt > 0) {
-            hipLaunchKernelGGL(mac_filter_kernel<T>, dim3(tiles, lj.n_filt), dim3(threads), 0, e->stream,
+            hipLaunchKernelGGL(mac_filter_kernel<T>, dim3(tiles, lj.n_filt), dim3(threads), 0, e->ls,
                                (const FilterJob<T> *)(base + lj.filt_off), e->L, e->blockcounter, (int)age64);
         }
         if (lj.n_fade > 0) {
             if ((*err = allow_lds(kx, lds)) != hipSuccess) return;
-            hipLaunchKernelGGL(kx, dim3(lj.n_fade), dim3(NT), lds, e->stream,
+            hipLaunchKernelGGL(kx, dim3(lj.n_fade), dim3(NT), lds, e->ls,
                                (const FadeJob<T> *)(base + lj.fade_off), (const c2<T> *)e->d_tw);
         }
         if ((*err = hipGetLastError()) != hipSuccess) return;
@@ -342,9 +366,9 @@ int build_plan_t(bfhip_engine *e) {
             job.in_off = (int)srcs.size();
             for (size_t i = 0; i < f.in_ch.size(); i++) {
                 MixSrc<T> m;
-                m.spec = (const c2<T> *)e->d_ring + (size_t)f.in_ch[i] * e->N * L;
+                m.spec = (const c2<T> *)e->d_ring + (size_t)f.in_ch[i] * e->R * L;
                 m.scale = (T)(f.in_scale[i] * e->fmt[0][f.in_ch[i]].scale);      // bfrun.c:1641
-                m.R = e->N;
+                m.R = e->R;
                 srcs.push_back(m);
             }
             job.n_up = (int)f.in_f.size();
@@ -360,7 +384,7 @@ int build_plan_t(bfhip_engine *e) {
             fills[e->level[fi]].push_back(job);
         } else {
             const int ch = f.in_ch[0];
-            ring = (const c2<T> *)e->d_ring + (size_t)ch * e->N * L;
+            ring = (const c2<T> *)e->d_ring + (size_t)ch * e->R * L;
             ring_id = ch; rdelay = delay;
             rscale = f.in_scale[0] * e->fmt[0][ch].scale;                         // bfrun.c:1664
         }
@@ -372,7 +396,7 @@ int build_plan_t(bfhip_engine *e) {
 
         if (needY) {
             FilterJob<T> job;
-            job.ring = ring; job.R = e->N; job.delay = rdelay; job.scale = (T)rscale;
+            job.ring = ring; job.R = owner ? e->N : e->R; job.delay = rdelay; job.scale = (T)rscale;
             job.H = f.coeff < 0 ? nullptr : (const c2<T> *)e->coeffs[f.coeff].d_H;
             job.P = P; job.kind = f.coeff < 0 ? TERM_DIRAC : TERM_COEFF;
             job.Y = Yptr(fi);
@@ -408,7 +432,7 @@ int build_plan_t(bfhip_engine *e) {
                 MacEntry<T> ne;
                 memset(&ne, 0, sizeof(ne));
                 ne.ring = needY ? Yptr(fi) : ring;
-                ne.R = needY ? 1 : e->N;
+                ne.R = needY ? 1 : (owner ? e->N : e->R);
                 ne.delay = needY ? 0 : rdelay;
                 for (int q = 0; q < OG; q++) ne.term[q].kind = TERM_NONE;
                 per_group[g].push_back(ne);
@@ -429,13 +453,22 @@ int build_plan_t(bfhip_engine *e) {
         }
     }
 
+    for (auto &v : per_group) {
+        for (auto &en : v) {
+            bool dense = en.maxP > 0;
+            for (int q = 0; q < OG; q++) dense = dense && en.term[q].kind == TERM_COEFF && en.term[q].P == en.maxP;
+            en.dense = dense ? 1 : 0;
+        }
+    }
+    if (const char *env = getenv("BFHIP_MAC_NT")) e->mac_nt = atoi(env) != 0;
+
     // chunking: enough workgroups to fill 256 CUs several times over
     e->mac_threads = std::min(256, std::max(64, e->L / (int)(16 / sizeof(c2<T>))));
     const int bins_per_wg = e->mac_threads * (int)(16 / sizeof(c2<T>));
     e->n_tiles = (e->L + bins_per_wg - 1) / bins_per_wg;
     size_t max_entries = 1;
     for (auto &v : per_group) max_entries = std::max(max_entries, v.size());
-    int target_wgs = 4096;
+    int target_wgs = 2048;
     if (const char *env = getenv("BFHIP_MAC_TARGET_WGS")) target_wgs = std::max(1, atoi(env));
     int S = (target_wgs + e->n_tiles * e->n_groups - 1) / (e->n_tiles * e->n_groups);
     S = std::max(1, std::min<int>(S, (int)max_entries));
@@ -500,14 +533,17 @@ int build_plan_t(bfhip_engine *e) {
         HIPCHK(hipMalloc(&e->d_jobs, blob.size()));
         e->jobs_cap = blob.size();
     }
-    HIPCHK(hipStreamSynchronize(e->stream));
+    { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
     if (!flat.empty()) HIPCHK(hipMemcpy(e->d_entries, flat.data(), flat.size() * sizeof(MacEntry<T>), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->d_chunks, chunks.data(), cb, hipMemcpyHostToDevice));
     if (!blob.empty()) HIPCHK(hipMemcpy(e->d_jobs, blob.data(), blob.size(), hipMemcpyHostToDevice));
     const size_t zb = (size_t)S * e->n_out_padded * L * sizeof(c2<T>);
     if (zb > e->zp_bytes) {
         if (e->d_Zp) (void)hipFree(e->d_Zp);
+        if (e->d_Zp2) (void)hipFree(e->d_Zp2);
+        e->d_Zp2 = nullptr;
         HIPCHK(hipMalloc(&e->d_Zp, zb));
+        if (e->pipelined) HIPCHK(hipMalloc(&e->d_Zp2, zb));
         e->zp_bytes = zb;
     }
 
@@ -567,7 +603,7 @@ int check_format(const bfhip_format *f) {
 
 int record(bfhip_engine *e, int idx) {
     if (!e->timing || e->ev_used >= MAX_TIMED) return BFHIP_OK;
-    HIPCHK(hipEventRecord(e->ev[(size_t)e->ev_used * 4 + idx], e->stream));
+    HIPCHK(hipEventRecord(e->ev[(size_t)e->ev_used * 6 + idx], e->ls));
     return BFHIP_OK;
 }
 
@@ -580,7 +616,7 @@ int ensure_ready(bfhip_engine *e) {
 
 int do_inputs(bfhip_engine *e, const void *rawin_dev) {
     hipError_t err = hipSuccess;
-    const int slot = (int)(e->blockcounter % (unsigned int)e->N);
+    const int slot = (int)(e->blockcounter % (unsigned int)e->R);
     DISPATCH(launch_fft_in, e, (const uint8_t *)rawin_dev, slot, &err);
     if (err != hipSuccess) return fail(BFHIP_EHIP, "fft_in launch: %s", hipGetErrorString(err));
     return BFHIP_OK;
@@ -687,8 +723,16 @@ bfhip_engine *bfhip_engine_create(int device, int length, int n_blocks, int real
 void bfhip_engine_destroy(bfhip_engine *e) {
     if (e == nullptr) return;
     (void)hipSetDevice(e->device);
-    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    (void)sync_all(e);
     for (auto &c : e->coeffs) if (c.d_H) (void)hipFree(c.d_H);
+    if (e->d_Zp2) (void)hipFree(e->d_Zp2);
+    for (int i = 0; i < 2; i++) {
+        if (e->ev_in[i]) (void)hipEventDestroy(e->ev_in[i]);
+        if (e->ev_mac[i]) (void)hipEventDestroy(e->ev_mac[i]);
+        if (e->ev_out[i]) (void)hipEventDestroy(e->ev_out[i]);
+    }
+    if (e->s_in) (void)hipStreamDestroy(e->s_in);
+    if (e->s_out) (void)hipStreamDestroy(e->s_out);
     void *ptrs[] = {e->d_tw, e->d_prev, e->d_ring, e->d_fmt[0], e->d_fmt[1], e->d_over, e->d_status,
                     e->d_bad, e->d_Zp, e->d_entries, e->d_chunks, e->d_rawin, e->d_rawout, e->d_taps,
                     e->d_fring, e->d_Y, e->d_Yold, e->d_evalprev, e->d_jobs,
@@ -797,11 +841,11 @@ static int add_coeff_common(bfhip_engine *e, const void *taps, bool on_device, i
     if (!on_device && n_taps > 0) {
         const size_t bytes = (size_t)n_taps * e->rs;
         if (bytes > e->taps_cap) {
-            if (e->d_taps) { HIPCHK(hipStreamSynchronize(e->stream)); (void)hipFree(e->d_taps); e->d_taps = nullptr; }
+            if (e->d_taps) { { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; } (void)hipFree(e->d_taps); e->d_taps = nullptr; }
             HIPCHK(hipMalloc(&e->d_taps, bytes));
             e->taps_cap = bytes;
         }
-        HIPCHK(hipStreamSynchronize(e->stream));
+        { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
         HIPCHK(hipMemcpy(e->d_taps, taps, bytes, hipMemcpyHostToDevice));
         src = e->d_taps;
     }
@@ -815,7 +859,7 @@ static int add_coeff_common(bfhip_engine *e, const void *taps, bool on_device, i
     if (!on_device) {
         // host-taps path is synchronous, like convolver_coeffs2cbuf: report NaN/Inf now
         int bad = 0;
-        HIPCHK(hipStreamSynchronize(e->stream));
+        { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
         HIPCHK(hipMemcpy(&bad, e->d_bad, sizeof(int), hipMemcpyDeviceToHost));
         if (bad) {
             HIPCHK(hipMemset(e->d_bad, 0, sizeof(int)));
@@ -842,17 +886,17 @@ int bfhip_engine_update_coeff_block(bfhip_engine *e, int coeff, int block, const
     HIPCHK(hipSetDevice(e->device));
     const size_t bytes = (size_t)e->L * e->rs;
     if (bytes > e->taps_cap) {
-        if (e->d_taps) { HIPCHK(hipStreamSynchronize(e->stream)); (void)hipFree(e->d_taps); e->d_taps = nullptr; }
+        if (e->d_taps) { { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; } (void)hipFree(e->d_taps); e->d_taps = nullptr; }
         HIPCHK(hipMalloc(&e->d_taps, bytes));
         e->taps_cap = bytes;
     }
-    HIPCHK(hipStreamSynchronize(e->stream));
+    { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
     HIPCHK(hipMemcpy(e->d_taps, taps, bytes, hipMemcpyHostToDevice));
     void *H = (unsigned char *)e->coeffs[coeff].d_H + (size_t)block * e->L * e->csize();
     hipError_t err = hipSuccess;
     DISPATCH(launch_coeff_prep, e, e->d_taps, e->L, 1.0, H, 1, &err);
     if (err != hipSuccess) return fail(BFHIP_EHIP, "coeff_prep launch: %s", hipGetErrorString(err));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
     return BFHIP_OK;
 }
 
@@ -889,7 +933,9 @@ int bfhip_engine_finalize(bfhip_engine *e) {
     HIPCHK(hipSetDevice(e->device));
     const size_t L = e->L;
     const size_t prev_b = (size_t)e->n_ch[0] * L * e->rs;
-    const size_t ring_b = (size_t)e->n_ch[0] * e->N * L * e->csize();
+    if (getenv("BFHIP_OVERLAP")) e->pipelined = true;
+    e->R = e->pipelined ? e->N + 1 : e->N;
+    const size_t ring_b = (size_t)e->n_ch[0] * e->R * L * e->csize();
     if (hipMalloc(&e->d_prev, prev_b) != hipSuccess || hipMalloc(&e->d_ring, ring_b) != hipSuccess)
         return fail(BFHIP_ENOMEM, "out of device memory for the spectrum rings");
     HIPCHK(hipMemset(e->d_prev, 0, prev_b));       // bfrun.c:1388: everything starts zeroed
@@ -935,12 +981,22 @@ int bfhip_engine_finalize(bfhip_engine *e) {
         if ((r = zalloc(&e->d_evalprev, (size_t)e->n_sinks * L * e->rs)) != BFHIP_OK) return r;
     }
     if ((r = dither_upload(e)) != BFHIP_OK) return r;
+    if (e->pipelined) {
+        HIPCHK(hipStreamCreateWithFlags(&e->s_in, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&e->s_out, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) {
+            HIPCHK(hipEventCreateWithFlags(&e->ev_in[i], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&e->ev_mac[i], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&e->ev_out[i], hipEventDisableTiming));
+        }
+    }
+    e->ls = e->stream;
     e->finalized = true;
     r = bfhip_engine_reset_overflow(e);
     if (r != BFHIP_OK) return r;
     // coefficient sets loaded from device memory are checked here
     int bad = 0;
-    HIPCHK(hipStreamSynchronize(e->stream));
+    { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
     HIPCHK(hipMemcpy(&bad, e->d_bad, sizeof(int), hipMemcpyDeviceToHost));
     if (bad) return fail(BFHIP_EINVAL, "NaN or Inf value among coefficients.");
     return build_plan(e);
@@ -978,6 +1034,7 @@ int bfhip_engine_set_fscale(bfhip_engine *e, int filter, int index, double scale
 int bfhip_engine_inputs_dev(bfhip_engine *e, const void *rawin_dev) {
     int r = ensure_ready(e);
     if (r != BFHIP_OK) return r;
+    e->ls = e->stream;
     return do_inputs(e, rawin_dev);
 }
 
@@ -1010,14 +1067,40 @@ int bfhip_engine_advance(bfhip_engine *e) {
 int bfhip_engine_block_dev(bfhip_engine *e, const void *rawin_dev, void *rawout_dev) {
     int r = ensure_ready(e);
     if (r != BFHIP_OK) return r;
+    const bool pipe = e->pipelined;
+    const int buf = (int)(e->blocks_done & 1);
+    void *Zp = (pipe && buf) ? e->d_Zp2 : e->d_Zp;
+
+    // K1 on the input stream.  It overwrites the ring slot of block t-R, last read by the MAC
+    // of block t-2 (the MAC of t-1 reaches back only N = R-1 blocks).
+    e->ls = pipe ? e->s_in : e->stream;
+    if (pipe && e->blocks_done >= 2) HIPCHK(hipStreamWaitEvent(e->s_in, e->ev_mac[buf], 0));
     if ((r = record(e, 0)) != BFHIP_OK) return r;
     if ((r = do_inputs(e, rawin_dev)) != BFHIP_OK) return r;
-    if ((r = do_levels(e)) != BFHIP_OK) return r;
     if ((r = record(e, 1)) != BFHIP_OK) return r;
-    if ((r = do_mac(e, e->d_Zp)) != BFHIP_OK) return r;
+    if (pipe) HIPCHK(hipEventRecord(e->ev_in[buf], e->s_in));
+
+    // per-filter kernels and the crossbar MAC on the main stream; Zp[buf] is free once the
+    // output pass of block t-2 has read it
+    e->ls = e->stream;
+    if (pipe) {
+        HIPCHK(hipStreamWaitEvent(e->stream, e->ev_in[buf], 0));
+        if (e->blocks_done >= 2) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_out[buf], 0));
+    }
+    if ((r = do_levels(e)) != BFHIP_OK) return r;
     if ((r = record(e, 2)) != BFHIP_OK) return r;
-    if ((r = do_outputs(e, e->d_Zp, (size_t)e->n_out_padded * e->L, e->n_chunks, 0, e->n_ch[1], rawout_dev)) != BFHIP_OK) return r;
+    if ((r = do_mac(e, Zp)) != BFHIP_OK) return r;
     if ((r = record(e, 3)) != BFHIP_OK) return r;
+    if (pipe) HIPCHK(hipEventRecord(e->ev_mac[buf], e->stream));
+
+    // K3 (+ dither pass) on the output stream
+    e->ls = pipe ? e->s_out : e->stream;
+    if (pipe) HIPCHK(hipStreamWaitEvent(e->s_out, e->ev_mac[buf], 0));
+    if ((r = record(e, 4)) != BFHIP_OK) return r;
+    if ((r = do_outputs(e, Zp, (size_t)e->n_out_padded * e->L, e->n_chunks, 0, e->n_ch[1], rawout_dev)) != BFHIP_OK) return r;
+    if ((r = record(e, 5)) != BFHIP_OK) return r;
+    if (pipe) HIPCHK(hipEventRecord(e->ev_out[buf], e->s_out));
+    e->ls = e->stream;
     if (e->timing && e->ev_used < MAX_TIMED) e->ev_used++;
     advance(e);
     return BFHIP_OK;
@@ -1026,7 +1109,7 @@ int bfhip_engine_block_dev(bfhip_engine *e, const void *rawin_dev, void *rawout_
 int bfhip_engine_sync(bfhip_engine *e) {
     if (!e || !e->finalized) return fail(BFHIP_ESTATE, "engine not finalized");
     HIPCHK(hipSetDevice(e->device));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
     int st = 0;
     HIPCHK(hipMemcpy(&st, e->d_status, sizeof(int), hipMemcpyDeviceToHost));
     if (st) HIPCHK(hipMemset(e->d_status, 0, sizeof(int)));
@@ -1038,20 +1121,22 @@ int bfhip_engine_block(bfhip_engine *e, const void *rawin, void *rawout, bfhip_o
     if (r != BFHIP_OK) return r;
     if (!rawin || !rawout) return fail(BFHIP_EINVAL, "block: null buffer");
     static_assert(sizeof(bfhip_overflow) == sizeof(DevOverflow), "overflow struct layout");
-    if (overflow) HIPCHK(hipMemcpyAsync(e->d_over, overflow, e->n_ch[1] * sizeof(DevOverflow), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(e->d_rawin, rawin, e->raw_bytes[0], hipMemcpyHostToDevice, e->stream));
+    hipStream_t sin = e->pipelined ? e->s_in : e->stream, sout = e->pipelined ? e->s_out : e->stream;
+    if (overflow) HIPCHK(hipMemcpyAsync(e->d_over, overflow, e->n_ch[1] * sizeof(DevOverflow), hipMemcpyHostToDevice, sout));
+    HIPCHK(hipMemcpyAsync(e->d_rawin, rawin, e->raw_bytes[0], hipMemcpyHostToDevice, sin));
     if ((r = bfhip_engine_block_dev(e, e->d_rawin, e->d_rawout)) != BFHIP_OK) return r;
-    HIPCHK(hipMemcpyAsync(rawout, e->d_rawout, e->raw_bytes[1], hipMemcpyDeviceToHost, e->stream));
-    if (overflow) HIPCHK(hipMemcpyAsync(overflow, e->d_over, e->n_ch[1] * sizeof(DevOverflow), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(rawout, e->d_rawout, e->raw_bytes[1], hipMemcpyDeviceToHost, sout));
+    if (overflow) HIPCHK(hipMemcpyAsync(overflow, e->d_over, e->n_ch[1] * sizeof(DevOverflow), hipMemcpyDeviceToHost, sout));
     return bfhip_engine_sync(e);
 }
 
 int bfhip_engine_set_stream(bfhip_engine *e, void *hip_stream) {
     if (!e) return fail(BFHIP_EINVAL, "null engine");
     HIPCHK(hipSetDevice(e->device));
-    if (e->stream) HIPCHK(hipStreamSynchronize(e->stream));
+    { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     e->stream = (hipStream_t)hip_stream;
+    e->ls = e->stream;
     e->own_stream = false;
     return BFHIP_OK;
 }
@@ -1059,7 +1144,7 @@ int bfhip_engine_set_stream(bfhip_engine *e, void *hip_stream) {
 int bfhip_engine_get_overflow(bfhip_engine *e, int ch, bfhip_overflow *of) {
     if (!e || !e->finalized || ch < 0 || ch >= e->n_ch[1] || !of) return fail(BFHIP_EINVAL, "get_overflow: bad argument");
     HIPCHK(hipSetDevice(e->device));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
     HIPCHK(hipMemcpy(of, e->d_over + ch, sizeof(DevOverflow), hipMemcpyDeviceToHost));
     return BFHIP_OK;
 }
@@ -1072,21 +1157,22 @@ int bfhip_engine_reset_overflow(bfhip_engine *e) {
         memset(&v[c], 0, sizeof(DevOverflow));
         v[c].max = overflow_max(e->fmt[1][c]);
     }
-    HIPCHK(hipStreamSynchronize(e->stream));
+    { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
     HIPCHK(hipMemcpy(e->d_over, v.data(), v.size() * sizeof(DevOverflow), hipMemcpyHostToDevice));
     return BFHIP_OK;
 }
 
 unsigned int bfhip_engine_blockcounter(const bfhip_engine *e) { return e ? e->blockcounter : 0; }
+int bfhip_engine_ring_depth(const bfhip_engine *e) { return e ? e->R : 0; }
 
 int bfhip_engine_enable_timing(bfhip_engine *e, int on) {
     if (!e) return fail(BFHIP_EINVAL, "null engine");
     HIPCHK(hipSetDevice(e->device));
     if (on && e->ev.empty()) {
-        e->ev.resize((size_t)MAX_TIMED * 4);
+        e->ev.resize((size_t)MAX_TIMED * 6);
         for (auto &x : e->ev) HIPCHK(hipEventCreate(&x));
     }
-    if (e->stream) HIPCHK(hipStreamSynchronize(e->stream));
+    { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
     e->timing = on != 0;
     e->ev_used = 0;
     return BFHIP_OK;
@@ -1095,12 +1181,12 @@ int bfhip_engine_enable_timing(bfhip_engine *e, int on) {
 int bfhip_engine_get_timing(bfhip_engine *e, double ms[4]) {
     if (!e || !ms) return fail(BFHIP_EINVAL, "get_timing: bad argument");
     HIPCHK(hipSetDevice(e->device));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
     ms[0] = ms[1] = ms[2] = 0; ms[3] = e->ev_used;
     for (int i = 0; i < e->ev_used; i++) {
         for (int k = 0; k < 3; k++) {
             float t = 0;
-            HIPCHK(hipEventElapsedTime(&t, e->ev[(size_t)i * 4 + k], e->ev[(size_t)i * 4 + k + 1]));
+            HIPCHK(hipEventElapsedTime(&t, e->ev[(size_t)i * 6 + 2 * k], e->ev[(size_t)i * 6 + 2 * k + 1]));
             ms[k] += t;
         }
     }
@@ -1120,12 +1206,13 @@ int bfhip_engine_algorithmic_bytes(bfhip_engine *e, double bytes[2]) {
 int bfhip_engine_read_output_spectrum(bfhip_engine *e, int ch, void *dst) {
     if (!e || !e->finalized || ch < 0 || ch >= e->n_ch[1] || !dst) return fail(BFHIP_EINVAL, "read_output_spectrum: bad argument");
     HIPCHK(hipSetDevice(e->device));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
     const size_t row = (size_t)e->L * e->csize();
     std::vector<unsigned char> tmp(row);
     memset(dst, 0, row);
     for (int c = 0; c < e->n_chunks; c++) {
-        HIPCHK(hipMemcpy(tmp.data(), (unsigned char *)e->d_Zp + ((size_t)c * e->n_out_padded + ch) * row, row, hipMemcpyDeviceToHost));
+        const unsigned char *zp = (const unsigned char *)((e->pipelined && e->d_Zp2 && ((e->blocks_done - 1) & 1)) ? e->d_Zp2 : e->d_Zp);
+        HIPCHK(hipMemcpy(tmp.data(), zp + ((size_t)c * e->n_out_padded + ch) * row, row, hipMemcpyDeviceToHost));
         const size_t n = (size_t)2 * e->L;
         if (e->rs == 4) for (size_t i = 0; i < n; i++) ((float *)dst)[i] += ((float *)tmp.data())[i];
         else for (size_t i = 0; i < n; i++) ((double *)dst)[i] += ((double *)tmp.data())[i];
@@ -1134,11 +1221,11 @@ int bfhip_engine_read_output_spectrum(bfhip_engine *e, int ch, void *dst) {
 }
 
 int bfhip_engine_read_ring_slot(bfhip_engine *e, int ch, int slot, void *dst) {
-    if (!e || !e->finalized || ch < 0 || ch >= e->n_ch[0] || slot < 0 || slot >= e->N || !dst) return fail(BFHIP_EINVAL, "read_ring_slot: bad argument");
+    if (!e || !e->finalized || ch < 0 || ch >= e->n_ch[0] || slot < 0 || slot >= e->R || !dst) return fail(BFHIP_EINVAL, "read_ring_slot: bad argument");
     HIPCHK(hipSetDevice(e->device));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
     const size_t row = (size_t)e->L * e->csize();
-    HIPCHK(hipMemcpy(dst, (unsigned char *)e->d_ring + ((size_t)ch * e->N + slot) * row, row, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(dst, (unsigned char *)e->d_ring + ((size_t)ch * e->R + slot) * row, row, hipMemcpyDeviceToHost));
     return BFHIP_OK;
 }
 

@@ -50,7 +50,7 @@ template <typename T> struct MacEntry {
     int R;              // ring depth
     int delay;          // filter delay in blocks (bfrun.c:1579-1584)
     int maxP;           // max over terms of P
-    int pad;
+    int dense;          // all OG terms are coefficient terms with P == maxP: pipelined path
     MacTerm<T> term[OG];
 };
 
@@ -190,6 +190,30 @@ coeff_prep_kernel(const T *__restrict__ taps, int n_taps, T scale, c2<T> *__rest
     }
 }
 
+// 16-byte global load of V = 16/sizeof(c2<T>) spectrum elements.  The pointer comes out of a
+// plan struct, so the compiler cannot know its address space and would emit flat_load (which
+// also ties up lgkmcnt); the explicit global address space gives global_load_dwordx4.
+// NT: non-temporal hint for data that is streamed exactly once per block (coefficients).
+template <typename T, bool NT> struct Load16;
+template <bool NT> struct Load16<float, NT> {
+    static __device__ __forceinline__ void get(const c2<float> *p, c2<float> *o) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(1))) const v4f *gp;
+        v4f q;
+        if (NT) q = __builtin_nontemporal_load((gp)(const void *)p); else q = *(gp)(const void *)p;
+        o[0] = mk<float>(q.x, q.y); o[1] = mk<float>(q.z, q.w);
+    }
+};
+template <bool NT> struct Load16<double, NT> {
+    static __device__ __forceinline__ void get(const c2<double> *p, c2<double> *o) {
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        typedef __attribute__((address_space(1))) const v2d *gp;
+        v2d q;
+        if (NT) q = __builtin_nontemporal_load((gp)(const void *)p); else q = *(gp)(const void *)p;
+        o[0] = mk<double>(q.x, q.y);
+    }
+};
+
 // ------------------------------------------------------------------ K2: crossbar MAC
 
 // Z[o][k] (+)= sum over entries (ring, delay) and partitions p of
@@ -201,7 +225,7 @@ coeff_prep_kernel(const T *__restrict__ taps, int n_taps, T scale, c2<T> *__rest
 // need the same ring tile get the same blockIdx%8 (one XCD, adjacent dispatch) so that the
 // ring re-reads hit that XCD's L2.  Partial sums of the chunks go to Zp[chunk][o][k] and
 // are added up by the consumer (K3 or sum_partials_kernel): deterministic, no atomics.
-template <typename T>
+template <typename T, bool NT>
 __global__ __launch_bounds__(256) void
 mac_xbar_kernel(const MacEntry<T> *__restrict__ entries, const ChunkRange *__restrict__ chunks,
                 c2<T> *__restrict__ Zp, int L, int n_out_padded, int n_groups, int n_chunks,
@@ -232,6 +256,41 @@ mac_xbar_kernel(const MacEntry<T> *__restrict__ entries, const ChunkRange *__res
         const int R = E->R, delay = E->delay;
         int maxP = E->maxP;
         if (maxP > age - delay) maxP = age - delay;     // blocks that exist yet (procblocks)
+        if (E->dense) {
+            // The crossbar case: OG coefficient terms of equal length.  Per partition one ring
+            // load and OG coefficient loads (1 KiB per wave each) are issued back to back from
+            // wave-uniform bases + one shared lane offset, then accumulated as they land.
+            const c2<T> *Hs[OG];
+            T sc[OG];
+#pragma unroll
+            for (int j = 0; j < OG; j++) { Hs[j] = E->term[j].H; sc[j] = E->term[j].scale; }
+            for (int p = 0; p < maxP; p++) {
+                // byte offsets kept in 32 bits (N * L * 16 < 4 GiB) so that the loads take the
+                // scalar-base + 32-bit lane-offset form
+                const unsigned int slot = (t - (unsigned int)p - (unsigned int)delay) % (unsigned int)R;
+                const unsigned int xoff = (slot * (unsigned int)L + (unsigned int)k0) * (unsigned int)sizeof(c2<T>);
+                const unsigned int hoff = ((unsigned int)p * (unsigned int)L + (unsigned int)k0) * (unsigned int)sizeof(c2<T>);
+                c2<T> x[V], h[OG][V];
+                Load16<T, false>::get((const c2<T> *)((const char *)ring + xoff), x);
+#pragma unroll
+                for (int j = 0; j < OG; j++) Load16<T, NT>::get((const c2<T> *)((const char *)Hs[j] + hoff), h[j]);
+#pragma unroll
+                for (int j = 0; j < OG; j++) {
+                    {
+                        const T xr = x[0].x * sc[j], xi = x[0].y * sc[j];
+                        const T hsel = dc ? h[j][0].y : h[j][0].x;
+                        acc[j][0] += xr * h[j][0].x - (am * xi) * h[j][0].y;
+                        acc[j][1] += (am * xr) * h[j][0].y + xi * hsel;
+                    }
+                    if constexpr (V == 2) {
+                        const T xr = x[1].x * sc[j], xi = x[1].y * sc[j];
+                        acc[j][2] += xr * h[j][1].x - xi * h[j][1].y;
+                        acc[j][3] += xr * h[j][1].y + xi * h[j][1].x;
+                    }
+                }
+            }
+            continue;
+        }
         for (int p = 0; p < maxP; p++) {
             const unsigned int slot = (t - (unsigned int)p - (unsigned int)delay) % (unsigned int)R;
             c2<T> x[V];

@@ -135,7 +135,10 @@ int bfhip_engine_set_fscale(bfhip_engine *e, int filter, int index, double scale
 int bfhip_engine_block(bfhip_engine *e, const void *rawin, void *rawout,
                        bfhip_overflow overflow[]);
 
-/* Device-resident raw buffers, asynchronous on the engine's stream. */
+/* Device-resident raw buffers, asynchronous on the engine's stream; complete after
+   bfhip_engine_sync().  (BFHIP_OVERLAP=1 in the environment queues the three kernels of a block
+   on three engine-owned streams so that the FFTs of neighbouring blocks run beside the MAC;
+   measured slower than the plain sequence on MI355X, kept as an experiment -- DESIGN.md.) */
 int bfhip_engine_block_dev(bfhip_engine *e, const void *rawin_dev, void *rawout_dev);
 /* wait for the stream; returns accumulated status bits (and clears them) or an error */
 int bfhip_engine_sync(bfhip_engine *e);
@@ -160,6 +163,8 @@ int bfhip_engine_set_stream(bfhip_engine *e, void *hip_stream);
 int bfhip_engine_get_overflow(bfhip_engine *e, int out_channel, bfhip_overflow *of);
 int bfhip_engine_reset_overflow(bfhip_engine *e);     /* bf_reset_peak(), bfrun.c */
 unsigned int bfhip_engine_blockcounter(const bfhip_engine *e);
+/* depth of the input spectrum rings (n_blocks, plus one spare slot when the block is pipelined) */
+int bfhip_engine_ring_depth(const bfhip_engine *e);
 
 /* ---- measurement ----------------------------------------------------------------------- */
 

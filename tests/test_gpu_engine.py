@@ -71,7 +71,7 @@ def test_input_spectrum_matches_numpy(hip):
         ge.block(b)
         for ch in range(I):
             X = np.fft.rfft(np.concatenate([prev[:, ch], b[:, ch]]).astype(np.float64))
-            z = ge.ring_slot(ch, t % N).astype(np.complex128)
+            z = ge.ring_slot(ch, t % ge.ring_depth).astype(np.complex128)
             got = np.concatenate([[z[0].real], z[1:], [z[0].imag]])
             assert np.abs(got - X).max() / np.abs(X).max() < 2e-6
         prev = b
