@@ -462,13 +462,15 @@ int build_plan_t(bfhip_engine *e) {
     }
     if (const char *env = getenv("BFHIP_MAC_NT")) e->mac_nt = atoi(env) != 0;
 
-    // chunking: enough workgroups to fill 256 CUs several times over
+    // chunking: one fat workgroup per CU measured best on MI355X (tools/tune_mac.py): each wave
+    // keeps 18 KiB of loads in flight, so 4 waves per CU already saturate HBM, and fewer chunks
+    // mean fewer partial sums to write and re-read
     e->mac_threads = std::min(256, std::max(64, e->L / (int)(16 / sizeof(c2<T>))));
     const int bins_per_wg = e->mac_threads * (int)(16 / sizeof(c2<T>));
     e->n_tiles = (e->L + bins_per_wg - 1) / bins_per_wg;
     size_t max_entries = 1;
     for (auto &v : per_group) max_entries = std::max(max_entries, v.size());
-    int target_wgs = 2048;
+    int target_wgs = 256;
     if (const char *env = getenv("BFHIP_MAC_TARGET_WGS")) target_wgs = std::max(1, atoi(env));
     int S = (target_wgs + e->n_tiles * e->n_groups - 1) / (e->n_tiles * e->n_groups);
     S = std::max(1, std::min<int>(S, (int)max_entries));

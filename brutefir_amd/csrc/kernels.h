@@ -264,6 +264,7 @@ mac_xbar_kernel(const MacEntry<T> *__restrict__ entries, const ChunkRange *__res
             T sc[OG];
 #pragma unroll
             for (int j = 0; j < OG; j++) { Hs[j] = E->term[j].H; sc[j] = E->term[j].scale; }
+#pragma unroll 2
             for (int p = 0; p < maxP; p++) {
                 // byte offsets kept in 32 bits (N * L * 16 < 4 GiB) so that the loads take the
                 // scalar-base + 32-bit lane-offset form
