@@ -60,35 +60,61 @@ struct ChunkRange { int begin, end; };
 
 template <typename T>
 __device__ __forceinline__ T load_raw(const uint8_t *p, const DevFormat &f) {
-    uint8_t t[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) t[i] = 0;
-    if (f.swap && f.bytes != 3) {
-        for (int i = 0; i < f.bytes; i++) t[i] = p[f.bytes - 1 - i];
+    // word-sized fast paths for naturally aligned samples (the common S16/S24_4/S32/FLOAT
+    // layouts); everything else is assembled byte by byte
+    uint32_t lo = 0, hi = 0;
+    const uintptr_t a = (uintptr_t)p;
+    if (f.bytes == 4 && (a & 3) == 0) {
+        lo = *reinterpret_cast<const uint32_t *>(p);
+        if (f.swap) lo = __builtin_bswap32(lo);
+    } else if (f.bytes == 2 && (a & 1) == 0) {
+        lo = *reinterpret_cast<const uint16_t *>(p);
+        if (f.swap) lo = __builtin_bswap16((uint16_t)lo);
+    } else if (f.bytes == 8 && (a & 7) == 0) {
+        uint64_t q = *reinterpret_cast<const uint64_t *>(p);
+        if (f.swap) q = __builtin_bswap64(q);
+        lo = (uint32_t)q; hi = (uint32_t)(q >> 32);
     } else {
-        for (int i = 0; i < f.bytes; i++) t[i] = p[i];
+        uint8_t t[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) t[i] = 0;
+        if (f.swap && f.bytes != 3) {
+            for (int i = 0; i < f.bytes; i++) t[i] = p[f.bytes - 1 - i];
+        } else {
+            for (int i = 0; i < f.bytes; i++) t[i] = p[i];
+        }
+        if (f.bytes == 3) {
+            // packed 24 bit: into the top of an int32, arithmetic shift down (raw2real.h:106-142)
+            const uint32_t u = f.swap ? ((uint32_t)t[2] << 8 | (uint32_t)t[1] << 16 | (uint32_t)t[0] << 24)
+                                      : ((uint32_t)t[0] << 8 | (uint32_t)t[1] << 16 | (uint32_t)t[2] << 24);
+            return (T)((int32_t)u >> 8);
+        }
+        lo = (uint32_t)t[0] | (uint32_t)t[1] << 8 | (uint32_t)t[2] << 16 | (uint32_t)t[3] << 24;
+        hi = (uint32_t)t[4] | (uint32_t)t[5] << 8 | (uint32_t)t[6] << 16 | (uint32_t)t[7] << 24;
     }
-    const uint32_t lo = (uint32_t)t[0] | (uint32_t)t[1] << 8 | (uint32_t)t[2] << 16 | (uint32_t)t[3] << 24;
     if (f.isfloat) {
         if (f.bytes == 4) return (T)__uint_as_float(lo);
-        const uint32_t hi = (uint32_t)t[4] | (uint32_t)t[5] << 8 | (uint32_t)t[6] << 16 | (uint32_t)t[7] << 24;
         return (T)__longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
     }
     switch (f.bytes) {
-    case 1: return (T)(int8_t)t[0];
+    case 1: return (T)(int8_t)(lo & 0xff);
     case 2: return (T)(int16_t)(lo & 0xffff);
-    case 3: {
-        // packed 24 bit: into the top of an int32, arithmetic shift down (raw2real.h:106-142)
-        const uint32_t u = f.swap ? ((uint32_t)t[2] << 8 | (uint32_t)t[1] << 16 | (uint32_t)t[0] << 24)
-                                  : ((uint32_t)t[0] << 8 | (uint32_t)t[1] << 16 | (uint32_t)t[2] << 24);
-        return (T)((int32_t)u >> 8);
-    }
     default: return (T)(int32_t)lo;
     }
 }
 
+// t[] holds the sample's bytes in little-endian order
 __device__ __forceinline__ void store_raw_bytes(uint8_t *p, const uint8_t *t, int bytes, int swap) {
-    if (swap) {
+    const uintptr_t a = (uintptr_t)p;
+    if (bytes == 4 && (a & 3) == 0) {
+        uint32_t u = (uint32_t)t[0] | (uint32_t)t[1] << 8 | (uint32_t)t[2] << 16 | (uint32_t)t[3] << 24;
+        if (swap) u = __builtin_bswap32(u);
+        *reinterpret_cast<uint32_t *>(p) = u;
+    } else if (bytes == 2 && (a & 1) == 0) {
+        uint16_t u = (uint16_t)((uint32_t)t[0] | (uint32_t)t[1] << 8);
+        if (swap) u = __builtin_bswap16(u);
+        *reinterpret_cast<uint16_t *>(p) = u;
+    } else if (swap) {
         for (int i = 0; i < bytes; i++) p[i] = t[bytes - 1 - i];
     } else {
         for (int i = 0; i < bytes; i++) p[i] = t[i];
