@@ -144,20 +144,40 @@ def main():
     n_pool = 4
     raw_in = synth_raw_blocks(torch, n_pool, L, I, device)
     raw_out = torch.zeros(L, O, dtype=torch.int32, device=device)
+    pipelined = world > 1 and backend == "nccl" and not os.environ.get("BFHIP_BENCH_SYNC_COLLECTIVE")
     if world > 1:
-        z_part = torch.zeros(O, L, 2, dtype=torch.float32, device=device)
-        z_loc = torch.zeros(co, L, 2, dtype=torch.float32, device=device)
+        z_part = [torch.zeros(O, L, 2, dtype=torch.float32, device=device) for _ in range(2)]
+        z_loc = [torch.zeros(co, L, 2, dtype=torch.float32, device=device) for _ in range(2)]
+    pending = []
+
+    def finish(item):
+        work, b = item
+        work.wait()                              # current stream waits for the collective
+        eng.outputs_dev(z_loc[b], fo, co, raw_out)
 
     def step(k):
         src = raw_in[k % n_pool]
         if world == 1:
             eng.block_dev(src, raw_out)
+            return
+        b = k & 1
+        eng.inputs_dev(src)
+        eng.mac_dev(z_part[b])
+        eng.advance()
+        if pipelined:
+            # the mix-down of block k runs on RCCL's stream beside the FFT/MAC of block k+1;
+            # block k's inverse FFT is queued one step later (all inside the timed region)
+            work = dist.reduce_scatter_tensor(z_loc[b], z_part[b], async_op=True)
+            if pending:
+                finish(pending.pop())
+            pending.append((work, b))
         else:
-            eng.inputs_dev(src)
-            eng.mac_dev(z_part)
-            sharding.mixdown(z_part, z_loc)
-            eng.outputs_dev(z_loc, fo, co, raw_out)
-            eng.advance()
+            sharding.mixdown(z_part[b], z_loc[b])
+            eng.outputs_dev(z_loc[b], fo, co, raw_out)
+
+    def drain():
+        while pending:
+            finish(pending.pop())
 
     def fence():
         torch.cuda.synchronize()
@@ -167,12 +187,14 @@ def main():
 
     for k in range(args.warmup):
         step(k)
+    drain()
     fence()
     if world == 1:
         eng.enable_timing(True)
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(args.warmup + k)
+    drain()
     fence()
     el = time.perf_counter() - t0
     if dist is not None:
@@ -194,18 +216,26 @@ def main():
             "config": {"workload": "%d-in/%d-out full crossbar, %d taps (%d x %d partitions), "
                                    "%s, %d filters" % (I, O, L * N, L, N, fmt, I * O),
                        "baseline_config": "configs[2]" if args.workload == "C" else "configs[1]",
-                       "parallelism": "input-sharded x%d + reduce-scatter" % world if world > 1
+                       "parallelism": ("input-sharded x%d + RCCL reduce-scatter%s"
+                                       % (world, " (overlapped with the next block)" if pipelined else ""))
+                                      if world > 1
                                       else "single GPU",
                        "status_bits": status},
             "hbm_gbs_algorithmic": alg["block"] / (ms * 1e-3) / 1e9 if world == 1 else None,
         }
         if world == 1:
             tm = eng.timing()
+            traffic = None
+            tp = os.path.join(ROOT, "profiles", "traffic_config%s.json" % args.workload)
+            if os.path.exists(tp):
+                # HBM bytes per MAC launch from the committed rocprofv3 PMC passes of this very
+                # workload (counters cannot be read from inside this process)
+                traffic = json.load(open(tp))["traffic_bytes_per_launch"]
             mac_s = tm["mac_ms"] * 1e-3
             ach = alg["mac"] / mac_s / 1e9 if mac_s > 0 else None
             out["roofline"] = {"bound": "hbm", "kernel": "mac_xbar_kernel", "achieved": ach,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": None,
+                               "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": traffic,
                                "algorithmic_bytes_per_launch": alg["mac"],
                                "avg_launch_ms": tm["mac_ms"], "launches": tm["launches"],
                                "fft_in_ms": tm["fft_in_ms"], "ifft_out_ms": tm["ifft_out_ms"]}

@@ -38,8 +38,9 @@ def mixdown(z_partial, z_local, group=None):
     """
     import torch.distributed as dist
     if dist.get_backend(group) == "gloo":
-        # gloo has no reduce_scatter: all-reduce then slice (CPU rehearsal only)
-        tmp = z_partial.clone()
+        # gloo has no reduce_scatter: all-reduce on the host, then slice (rehearsal only:
+        # CPU tests, or several ranks sharing one GPU where RCCL refuses duplicate devices)
+        tmp = z_partial.detach().cpu().clone()
         dist.all_reduce(tmp, group=group)
         n = z_local.shape[0]
         r = dist.get_rank(group)

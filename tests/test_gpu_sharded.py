@@ -1,0 +1,98 @@
+"""GPU rehearsal of the multi-GPU decomposition on ONE card: two ranks (gloo, both on cuda:0)
+each run the HIP engine on half of the inputs, exchange partial output spectra through
+brutefir_amd.sharding.mixdown and inverse-transform their half of the outputs; the result must
+equal one engine running the whole crossbar.  (RCCL itself cannot be exercised with two ranks
+on one device; the 8-GPU run is the driver's.)"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+L, N, I, O = 1024, 4, 4, 4
+FMT = "S24_4LE"
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "oracle"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    import brutefir_amd as bf
+    from brutefir_amd import sharding
+    import cases
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    fi, ci, fo, co = sharding.shard_crossbar(I, O, world, rank)
+    e = bf.Engine(L, N, 4, ci, O)
+    fm = bf.interleaved_formats(FMT, I)
+    for c in range(ci):
+        e.set_format(bf.IN, c, fm[fi + c])
+    for c, f in enumerate(bf.interleaved_formats("FLOAT_LE", O)):
+        e.set_format(bf.OUT, c, f)
+    for o in range(O):
+        for i in range(fi, fi + ci):
+            h = cases.make_ir(np.random.default_rng(4321 + o * I + i), L * N, I)
+            e.add_filter(in_ch=[i - fi], out_ch=[o], coeff=e.add_coeff(h))
+    e.finalize()
+    e.set_stream(torch.cuda.current_stream().cuda_stream)
+    z_part = torch.zeros(O, L, 2, dtype=torch.float32, device=dev)
+    z_loc = torch.zeros(co, L, 2, dtype=torch.float32, device=dev)
+    raw_out = torch.zeros(L, O, dtype=torch.float32, device=dev)
+    outs = []
+    for blk in cases.raw_blocks(1234, N + 3, L, I, FMT):
+        src = torch.from_numpy(blk).to(dev)
+        e.inputs_dev(src)
+        e.mac_dev(z_part)
+        torch.cuda.synchronize()
+        sharding.mixdown(z_part, z_loc)
+        e.outputs_dev(z_loc, fo, co, raw_out)
+        e.advance()
+        torch.cuda.synchronize()
+        outs.append(raw_out[:, fo:fo + co].cpu().numpy().copy())
+    st = e.sync()
+    dist.destroy_process_group()
+    q.put((rank, fo, co, st, np.stack(outs)))
+
+
+def test_two_ranks_on_one_gpu_match_the_unsharded_engine(hip):
+    import torch.multiprocessing as mp
+    import cases
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    full, _ = cases.crossbar(hip.Engine, L, N, 4, I, O, FMT, "FLOAT_LE")
+    want = []
+    for blk in cases.raw_blocks(1234, N + 3, L, I, FMT):
+        st, raw = full.block(blk)
+        assert st == 0
+        want.append(np.frombuffer(raw.tobytes(), np.float32).reshape(L, O).copy())
+    want = np.stack(want)
+    for rank, fo, co, st, got in res:
+        assert st == 0
+        err = cases.rel_rms(got, want[:, :, fo:fo + co])
+        assert err <= 1e-6, (rank, err)        # same kernels, only the summation order differs
