@@ -117,6 +117,7 @@ struct bfhip_engine {
     // filters that need more than the shared-ring fast path (SURVEY A3 N-way mix, A7, A8)
     std::vector<int> level, owner_index, y_index, sink_index, fade_index;
     std::vector<char> is_source;
+    std::vector<void *> promoted;      // private ring given to a shared-ring filter at run time
     int n_levels = 0, n_owners = 0, n_y = 0, n_sinks = 0, n_fadeable = 0;
     void *d_fring = nullptr;       // [n_owners][N][L] complex: private rings
     void *d_Y = nullptr;           // [n_y][L] complex: materialised filter outputs
@@ -344,7 +345,7 @@ int build_plan_t(bfhip_engine *e) {
         if (f.coeff >= (int)e->coeffs.size()) return fail(BFHIP_EINVAL, "filter %d: bad coeff", fi);
         const int delay = clamp_delay(e, f.delayblocks);
         const int P = f.coeff < 0 ? 1 : cblocks_of(e, f.coeff, delay);
-        const bool owner = e->owner_index[fi] >= 0;
+        const bool owner = e->owner_index[fi] >= 0 || e->promoted[fi] != nullptr;
         const bool fading = f.crossfade && f.prevcoeff != f.coeff;
         const bool needY = e->is_source[fi] || fading;
         if (fading) e->any_fading = true;
@@ -356,7 +357,8 @@ int build_plan_t(bfhip_engine *e) {
         int rdelay;
         double rscale;
         if (owner) {
-            ring = (const c2<T> *)e->d_fring + (size_t)e->owner_index[fi] * e->N * L;
+            ring = e->promoted[fi] ? (const c2<T> *)e->promoted[fi]
+                                   : (const c2<T> *)e->d_fring + (size_t)e->owner_index[fi] * e->N * L;
             ring_id = I + fi; rdelay = 0; rscale = 1.0;
             FillJob<T> job;
             memset(&job, 0, sizeof(job));
@@ -727,6 +729,7 @@ void bfhip_engine_destroy(bfhip_engine *e) {
     (void)hipSetDevice(e->device);
     (void)sync_all(e);
     for (auto &c : e->coeffs) if (c.d_H) (void)hipFree(c.d_H);
+    for (void *p : e->promoted) if (p) (void)hipFree(p);
     if (e->d_Zp2) (void)hipFree(e->d_Zp2);
     for (int i = 0; i < 2; i++) {
         if (e->ev_in[i]) (void)hipEventDestroy(e->ev_in[i]);
@@ -958,6 +961,7 @@ int bfhip_engine_finalize(bfhip_engine *e) {
         const int F = (int)e->filters.size();
         e->level.assign(F, 0); e->owner_index.assign(F, -1); e->y_index.assign(F, -1);
         e->sink_index.assign(F, -1); e->fade_index.assign(F, -1); e->is_source.assign(F, 0);
+        e->promoted.assign(F, nullptr);
         e->n_owners = e->n_y = e->n_sinks = e->n_fadeable = 0;
         int maxlevel = 0;
         for (int fi = 0; fi < F; fi++) {
@@ -1004,6 +1008,37 @@ int bfhip_engine_finalize(bfhip_engine *e) {
     return build_plan(e);
 }
 
+// Exact history semantics for run-time changes (SURVEY 7 "hard parts"): the reference scales
+// and delays a block when it ENTERS the filter's ring, so a change must not touch the blocks
+// already in it.  A filter that shares its input's ring gets its own ring at that moment.
+static int promote_filter(bfhip_engine *e, int fi) {
+    if (!e->finalized || e->owner_index[fi] >= 0 || e->promoted[fi]) return BFHIP_OK;
+    const Filter &f = e->filters[fi];
+    HIPCHK(hipSetDevice(e->device));
+    const size_t bytes = (size_t)e->N * e->L * e->csize();
+    void *ring = nullptr;
+    if (hipMalloc(&ring, bytes) != hipSuccess) return fail(BFHIP_ENOMEM, "out of device memory for a private ring");
+    HIPCHK(hipMemsetAsync(ring, 0, bytes, e->stream));
+    const int ch = f.in_ch[0];
+    const int delay = clamp_delay(e, f.delayblocks);
+    const double sc = f.in_scale[0] * e->fmt[0][ch].scale;
+    const int n_valid = (int)std::min<unsigned long long>(e->blocks_done, (unsigned long long)e->N);
+    if (n_valid > 0) {
+        const dim3 grid((e->L + 255) / 256, n_valid);
+        const unsigned char *src = (const unsigned char *)e->d_ring + (size_t)ch * e->R * e->L * e->csize();
+        if (e->rs == 4)
+            hipLaunchKernelGGL(promote_ring_kernel<float>, grid, dim3(256), 0, e->stream, (const c2<float> *)src, e->R,
+                               (c2<float> *)ring, e->N, e->L, e->blockcounter, delay, (float)sc, n_valid);
+        else
+            hipLaunchKernelGGL(promote_ring_kernel<double>, grid, dim3(256), 0, e->stream, (const c2<double> *)src, e->R,
+                               (c2<double> *)ring, e->N, e->L, e->blockcounter, delay, sc, n_valid);
+        HIPCHK(hipGetLastError());
+    }
+    e->promoted[fi] = ring;
+    e->plan_dirty = true;
+    return BFHIP_OK;
+}
+
 int bfhip_engine_set_coeff(bfhip_engine *e, int filter, int coeff) {
     if (!e || filter < 0 || filter >= (int)e->filters.size() || coeff >= (int)e->coeffs.size())
         return fail(BFHIP_EINVAL, "set_coeff: bad argument");
@@ -1013,7 +1048,11 @@ int bfhip_engine_set_coeff(bfhip_engine *e, int filter, int coeff) {
 
 int bfhip_engine_set_delayblocks(bfhip_engine *e, int filter, int blocks) {
     if (!e || filter < 0 || filter >= (int)e->filters.size()) return fail(BFHIP_EINVAL, "set_delayblocks: bad argument");
-    if (e->filters[filter].delayblocks != blocks) { e->filters[filter].delayblocks = blocks; e->plan_dirty = true; }
+    if (e->filters[filter].delayblocks != blocks) {
+        int r = promote_filter(e, filter);
+        if (r != BFHIP_OK) return r;
+        e->filters[filter].delayblocks = blocks; e->plan_dirty = true;
+    }
     return BFHIP_OK;
 }
 
@@ -1021,7 +1060,13 @@ int bfhip_engine_set_scale(bfhip_engine *e, int filter, int io, int index, doubl
     if (!e || filter < 0 || filter >= (int)e->filters.size() || io < 0 || io > 1) return fail(BFHIP_EINVAL, "set_scale: bad argument");
     auto &v = io == 0 ? e->filters[filter].in_scale : e->filters[filter].out_scale;
     if (index < 0 || index >= (int)v.size()) return fail(BFHIP_EINVAL, "set_scale: bad index");
-    if (v[index] != scale) { v[index] = scale; e->plan_dirty = true; }
+    if (v[index] != scale) {
+        if (io == 0) {
+            int r = promote_filter(e, filter);
+            if (r != BFHIP_OK) return r;
+        }
+        v[index] = scale; e->plan_dirty = true;
+    }
     return BFHIP_OK;
 }
 

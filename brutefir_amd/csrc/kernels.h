@@ -514,6 +514,21 @@ ring_fill_kernel(const FillJob<T> *__restrict__ jobs, const MixSrc<T> *__restric
     }
 }
 
+// Turn a filter that shared its input's ring into a ring owner (first run-time change of its
+// input scale or delay): rebuild what the reference's private cbuf[n][] holds right now, i.e.
+// slot (t' + delay_old) mod N = scale_old * X[t'] for the last N blocks t' (bfrun.c:1600,1651-1656).
+template <typename T>
+__global__ __launch_bounds__(256) void
+promote_ring_kernel(const c2<T> *__restrict__ src, int R, c2<T> *__restrict__ dst, int N, int L,
+                    unsigned int t, int delay_old, T scale_old, int n_valid) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;                     // how many blocks back (0 = most recent)
+    if (k >= L || j >= n_valid) return;
+    const unsigned int tb = t - 1u - (unsigned int)j;
+    const c2<T> v = src[(size_t)(tb % (unsigned int)R) * L + k];
+    dst[(size_t)((tb + (unsigned int)delay_old) % (unsigned int)N) * L + k] = mk<T>(v.x * scale_old, v.y * scale_old);
+}
+
 // ------------------------------------------------------------------ per-filter MAC (materialised outputs)
 
 // Y_f[k] = sum_p scale * ring[(t - p - delay) mod R][k] * H[p][k]   (or the dirac spectrum)

@@ -310,3 +310,30 @@ def test_hp_tpdf_dither_f32_within_one_lsb(hip):
         assert gs == os_ == 0
         d = np.abs(g.view(np.int16).astype(int) - o.view(np.int16).astype(int))
         assert d.max() <= 2 and (d > 0).mean() < 0.05
+
+
+@pytest.mark.parametrize("rs", [4, 8])
+def test_runtime_scale_and_delay_changes_keep_history_semantics(hip, rs):
+    """bflogic_cli changing a filter's input attenuation / delay while it runs: the reference
+    scales and delays a block when it ENTERS the filter's ring, so blocks already in the ring
+    keep their old scale and slot (bfrun.c:1600,1651-1656).  Output scale changes act at once."""
+    L, N = 128, 6
+    coeffs = [(_ir(70, L * N), 1.0, 0), (_ir(71, L * N), 1.0, 0)]
+    filters = [
+        dict(in_ch=[0], out_ch=[0], coeff=0),
+        dict(in_ch=[1], out_ch=[1], coeff=1, delayblocks=1),
+        dict(in_ch=[0], out_ch=[1], coeff=1, in_scale=[0.5]),
+    ]
+
+    def control(b, eng):
+        if b == 4:
+            eng.set_scale(0, 0, 0, 0.25)        # input attenuation of filter 0
+        if b == 6:
+            eng.set_delayblocks(1, 3)           # more delay: leaves stale slots behind
+            eng.set_scale(2, 1, 0, -2.0)        # output scale of filter 2
+        if b == 9:
+            eng.set_delayblocks(1, 0)
+            eng.set_scale(0, 0, 0, 1.0)
+        if b == 10:
+            eng.set_scale(2, 0, 0, 1.5)
+    _compare(hip, _spec(L, N, rs, 2, 2, filters, coeffs), 20, control=control)
