@@ -27,7 +27,11 @@ WORKLOADS = {
     # name: (I, O, L, N, realsize, raw format)
     "C": (64, 64, 8192, 32, 4, "S24_4LE"),     # BASELINE.json configs[2], the headline
     "B": (8, 8, 8192, 8, 4, "S24_4LE"),        # configs[1]
+    # the remaining BASELINE.json configs are parity-test shapes; timing them is informative only
+    "D": (256, 256, 8192, 16, 4, "S24_4LE"),   # configs[3] on ONE GPU: 256 one-to-one filters
+    "E": (2, 2, 8192, 128, 8, "FLOAT64_LE"),   # configs[4], uniform stand-in, float64
 }
+DIAGONAL = {"D"}
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -132,9 +136,12 @@ def main():
         eng.set_format(bf.OUT, c, f)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     taps = L * N
+    tdt = torch.float32 if rs == 4 else torch.float64
     for o in range(O):
         for i in range(fi, fi + ci):
-            h = synth_ir_dev(torch, 4321 + o * I + i, taps, I, device)
+            if args.workload in DIAGONAL and i != o:
+                continue
+            h = synth_ir_dev(torch, 4321 + o * I + i, taps, 1 if args.workload in DIAGONAL else I, device).to(tdt)
             c = eng.add_coeff_dev(h, taps)
             eng.add_filter(in_ch=[i - fi], out_ch=[o], coeff=c)
     torch.cuda.synchronize()
@@ -142,8 +149,14 @@ def main():
     alg = eng.algorithmic_bytes()
 
     n_pool = 4
-    raw_in = synth_raw_blocks(torch, n_pool, L, I, device)
-    raw_out = torch.zeros(L, O, dtype=torch.int32, device=device)
+    if fmt == "S24_4LE":
+        raw_in = synth_raw_blocks(torch, n_pool, L, I, device)
+        raw_out = torch.zeros(L, O, dtype=torch.int32, device=device)
+    else:
+        g = torch.Generator(device=device)
+        g.manual_seed(1234)
+        raw_in = (torch.randn(n_pool, L, I, generator=g, device=device, dtype=torch.float64) * 0.1).contiguous()
+        raw_out = torch.zeros(L, O, dtype=torch.float64, device=device)
     pipelined = world > 1 and backend == "nccl" and not os.environ.get("BFHIP_BENCH_SYNC_COLLECTIVE")
     if world > 1:
         z_part = [torch.zeros(O, L, 2, dtype=torch.float32, device=device) for _ in range(2)]
@@ -213,9 +226,12 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32" if rs == 4 else "f64",
             "data": "synthetic (seeded noise PCM, seeded decaying-noise IRs)",
-            "config": {"workload": "%d-in/%d-out full crossbar, %d taps (%d x %d partitions), "
-                                   "%s, %d filters" % (I, O, L * N, L, N, fmt, I * O),
-                       "baseline_config": "configs[2]" if args.workload == "C" else "configs[1]",
+            "config": {"workload": "%d-in/%d-out %s, %d taps (%d x %d partitions), "
+                                   "%s, %d filters" % (I, O, "one-to-one" if args.workload in DIAGONAL
+                                                       else "full crossbar", L * N, L, N, fmt,
+                                                       I if args.workload in DIAGONAL else I * O),
+                       "baseline_config": {"C": "configs[2]", "B": "configs[1]", "D": "configs[3] on one GPU",
+                                           "E": "configs[4] (uniform partitions)"}[args.workload],
                        "parallelism": ("input-sharded x%d + RCCL reduce-scatter%s"
                                        % (world, " (overlapped with the next block)" if pipelined else ""))
                                       if world > 1

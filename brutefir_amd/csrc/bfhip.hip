@@ -455,35 +455,76 @@ int build_plan_t(bfhip_engine *e) {
         }
     }
 
-    for (auto &v : per_group) {
-        for (auto &en : v) {
-            bool dense = en.maxP > 0;
-            for (int q = 0; q < OG; q++) dense = dense && en.term[q].kind == TERM_COEFF && en.term[q].P == en.maxP;
-            en.dense = dense ? 1 : 0;
-        }
-    }
-    if (const char *env = getenv("BFHIP_MAC_NT")) e->mac_nt = atoi(env) != 0;
-
-    // chunking: one fat workgroup per CU measured best on MI355X (tools/tune_mac.py): each wave
-    // keeps 18 KiB of loads in flight, so 4 waves per CU already saturate HBM, and fewer chunks
-    // mean fewer partial sums to write and re-read
+    // launch geometry: one fat workgroup per CU measured best on MI355X (tools/tune_mac.py): each
+    // wave keeps 18 KiB of loads in flight, so 4 waves per CU already saturate HBM, and fewer
+    // chunks mean fewer partial sums to write and re-read
     e->mac_threads = std::min(256, std::max(64, e->L / (int)(16 / sizeof(c2<T>))));
     const int bins_per_wg = e->mac_threads * (int)(16 / sizeof(c2<T>));
     e->n_tiles = (e->L + bins_per_wg - 1) / bins_per_wg;
-    size_t max_entries = 1;
-    for (auto &v : per_group) max_entries = std::max(max_entries, v.size());
     int target_wgs = 256;
     if (const char *env = getenv("BFHIP_MAC_TARGET_WGS")) target_wgs = std::max(1, atoi(env));
-    int S = (target_wgs + e->n_tiles * e->n_groups - 1) / (e->n_tiles * e->n_groups);
+    if (const char *env = getenv("BFHIP_MAC_NT")) e->mac_nt = atoi(env) != 0;
+    const int s_full = std::max(1, std::min(64, (target_wgs + e->n_tiles * e->n_groups - 1) / (e->n_tiles * e->n_groups)));
+    int S = s_full;
+    if (!getenv("BFHIP_MAC_TARGET_WGS")) {
+        // every chunk costs the output pass one more partial spectrum to read (~2 us measured);
+        // a workgroup streams ~1.35 GB/s per KiB it keeps in flight per wave (2 partitions x
+        // (1 ring + n coefficient loads) KiB; 25 GB/s at the crossbar's 18 KiB), the chip
+        // ~6.4 TB/s, and a launch is never shorter than ~13 us.  Pick the split that minimises
+        // MAC + output-pass time (matters for small crossbars; config C: S = 2).
+        double n_terms = 0, n_ent = 0;
+        for (auto &v : per_group)
+            for (auto &en : v) {
+                n_ent += 1;
+                for (int q = 0; q < OG; q++) n_terms += en.term[q].kind == TERM_COEFF ? 1 : 0;
+            }
+        const double rate = 1.35e9 * 2.0 * (1.0 + (n_ent > 0 ? n_terms / n_ent : 1.0));
+        double best = 1e30;
+        for (int c = 1; c <= s_full; c++) {
+            const double wgs = std::min(256.0, (double)e->n_tiles * e->n_groups * c);
+            const double t_mac = std::max(std::max(13e-6, bytes_H / 6.4e12), bytes_H / (wgs * rate));
+            const double t_out = 2e-6 * c;
+            if (t_mac + t_out < best - 1e-9) { best = t_mac + t_out; S = c; }
+        }
+    }
+
+    // few filters with many partitions (room correction): split entries along p until every
+    // group has S work items
+    for (auto &v : per_group) {
+        if (v.empty() || (int)v.size() >= S) continue;
+        const int parts = (S + (int)v.size() - 1) / (int)v.size();
+        std::vector<MacEntry<T>> split;
+        for (auto &en : v) {
+            const int len = en.maxP;
+            const int np = std::max(1, std::min(parts, len));
+            for (int q = 0; q < np; q++) {
+                MacEntry<T> sub = en;
+                sub.p0 = (int)((long)len * q / np);
+                sub.maxP = (int)((long)len * (q + 1) / np);
+                if (sub.maxP > sub.p0) split.push_back(sub);
+            }
+        }
+        v.swap(split);
+    }
+    size_t max_entries = 1;
+    for (auto &v : per_group) max_entries = std::max(max_entries, v.size());
     S = std::max(1, std::min<int>(S, (int)max_entries));
     e->n_chunks = S;
+
+    for (auto &v : per_group) {
+        for (auto &en : v) {
+            bool dense = en.maxP > en.p0;
+            for (int q = 0; q < OG; q++) dense = dense && en.term[q].kind == TERM_COEFF && en.term[q].P >= en.maxP;
+            en.dense = dense ? 1 : 0;
+        }
+    }
 
     std::vector<MacEntry<T>> flat;
     std::vector<ChunkRange> chunks((size_t)e->n_groups * S);
     for (int g = 0; g < e->n_groups; g++) {
         const auto &v = per_group[g];
         long total = 0;
-        for (auto &en : v) total += en.maxP;
+        for (auto &en : v) total += en.maxP - en.p0;
         const int base = (int)flat.size();
         size_t pos = 0;
         long acc = 0;
@@ -491,7 +532,7 @@ int build_plan_t(bfhip_engine *e) {
             ChunkRange cr;
             cr.begin = base + (int)pos;
             const long want = (total * (c + 1) + S - 1) / S;
-            while (pos < v.size() && (acc < want || c == S - 1)) { acc += v[pos].maxP; pos++; }
+            while (pos < v.size() && (acc < want || c == S - 1)) { acc += v[pos].maxP - v[pos].p0; pos++; }
             cr.end = base + (int)pos;
             chunks[(size_t)g * S + c] = cr;
         }

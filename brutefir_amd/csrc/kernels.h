@@ -49,7 +49,8 @@ template <typename T> struct MacEntry {
     const c2<T> *ring;  // [R][L] packed spectra of past blocks
     int R;              // ring depth
     int delay;          // filter delay in blocks (bfrun.c:1579-1584)
-    int maxP;           // max over terms of P
+    int p0;             // first partition this entry covers (entries may be split along p)
+    int maxP;           // one past the last partition: max over terms of P, or the split point
     int dense;          // all OG terms are coefficient terms with P == maxP: pipelined path
     MacTerm<T> term[OG];
 };
@@ -280,6 +281,7 @@ mac_xbar_kernel(const MacEntry<T> *__restrict__ entries, const ChunkRange *__res
         const MacEntry<T> *E = &entries[e];
         const c2<T> *ring = E->ring;
         const int R = E->R, delay = E->delay;
+        const int p0 = E->p0;
         int maxP = E->maxP;
         if (maxP > age - delay) maxP = age - delay;     // blocks that exist yet (procblocks)
         if (E->dense) {
@@ -291,7 +293,7 @@ mac_xbar_kernel(const MacEntry<T> *__restrict__ entries, const ChunkRange *__res
 #pragma unroll
             for (int j = 0; j < OG; j++) { Hs[j] = E->term[j].H; sc[j] = E->term[j].scale; }
 #pragma unroll 2
-            for (int p = 0; p < maxP; p++) {
+            for (int p = p0; p < maxP; p++) {
                 // byte offsets kept in 32 bits (N * L * 16 < 4 GiB) so that the loads take the
                 // scalar-base + 32-bit lane-offset form
                 const unsigned int slot = (t - (unsigned int)p - (unsigned int)delay) % (unsigned int)R;
@@ -318,7 +320,7 @@ mac_xbar_kernel(const MacEntry<T> *__restrict__ entries, const ChunkRange *__res
             }
             continue;
         }
-        for (int p = 0; p < maxP; p++) {
+        for (int p = p0; p < maxP; p++) {
             const unsigned int slot = (t - (unsigned int)p - (unsigned int)delay) % (unsigned int)R;
             c2<T> x[V];
             {
