@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--workload", default="C", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-io", action="store_true",
+                    help="time bfhip_engine_block() with HOST raw buffers (PCIe both ways and a "
+                         "sync per block included) -- informative, never the headline value")
     args = ap.parse_args()
 
     import torch
@@ -168,10 +171,15 @@ def main():
         work.wait()                              # current stream waits for the collective
         eng.outputs_dev(z_loc[b], fo, co, raw_out)
 
+    host_in = [raw_in[i].cpu().numpy() for i in range(n_pool)] if args.host_io else None
+
     def step(k):
         src = raw_in[k % n_pool]
         if world == 1:
-            eng.block_dev(src, raw_out)
+            if args.host_io:
+                eng.block(host_in[k % n_pool])
+            else:
+                eng.block_dev(src, raw_out)
             return
         b = k & 1
         eng.inputs_dev(src)
@@ -239,6 +247,8 @@ def main():
                        "status_bits": status},
             "hbm_gbs_algorithmic": alg["block"] / (ms * 1e-3) / 1e9 if world == 1 else None,
         }
+        if args.host_io:
+            out["config"]["io"] = "host buffers through bfhip_engine_block (PCIe-inclusive)"
         if world == 1:
             tm = eng.timing()
             traffic = None
