@@ -87,6 +87,8 @@ def lib():
     L.bfhip_engine_add_coeff.argtypes = [vp, vp, ci, cd, ci]
     L.bfhip_engine_add_coeff_dev.argtypes = [vp, vp, ci, cd, ci]
     L.bfhip_engine_update_coeff_block.argtypes = [vp, ci, ci, vp]
+    L.bfhip_engine_add_coeff_processed.argtypes = [vp, vp, ci]
+    L.bfhip_engine_read_coeff_processed.argtypes = [vp, ci, vp]
     L.bfhip_engine_add_filter.argtypes = [vp, ci, ip, dp, ci, ip, dp, ci, ip, dp, ci, ci, ci]
     L.bfhip_engine_finalize.argtypes = [vp]
     L.bfhip_engine_set_coeff.argtypes = [vp, ci, ci]
@@ -189,6 +191,17 @@ class Engine:
     def add_coeff_dev(self, taps_dev, n_taps, scale=1.0, n_blocks=0):
         return _check(lib().bfhip_engine_add_coeff_dev(self.h, _ptr(taps_dev), n_taps, scale,
                                                        n_blocks))
+
+    def add_coeff_processed(self, cbufs):
+        """cbufs: [n_blocks, 2L] reals in the reference's internal layout"""
+        cbufs = np.ascontiguousarray(cbufs, self.dt)
+        return _check(lib().bfhip_engine_add_coeff_processed(self.h, _ptr(cbufs), cbufs.shape[0]))
+
+    def read_coeff_processed(self, coeff, n_blocks):
+        out = np.empty((n_blocks, 2 * self.L), self.dt)
+        got = _check(lib().bfhip_engine_read_coeff_processed(self.h, coeff, _ptr(out)))
+        assert got == n_blocks
+        return out
 
     def update_coeff_block(self, coeff, block, taps):
         taps = np.ascontiguousarray(taps, self.dt)

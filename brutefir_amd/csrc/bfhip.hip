@@ -925,6 +925,60 @@ int bfhip_engine_add_coeff_dev(bfhip_engine *e, const void *taps_dev, int n_taps
     return add_coeff_common(e, taps_dev, true, n_taps, scale, n_blocks);
 }
 
+int bfhip_engine_add_coeff_processed(bfhip_engine *e, const void *cbufs, int n_blocks) {
+    if (!e || !cbufs || n_blocks < 1) return fail(BFHIP_EINVAL, "add_coeff_processed: bad argument");
+    if (n_blocks > e->N) return fail(BFHIP_EINVAL, "coefficient set has %d blocks, engine has %d", n_blocks, e->N);
+    HIPCHK(hipSetDevice(e->device));
+    const size_t n = (size_t)n_blocks * 2 * e->L;
+    // convolver_verify_cbuf (fftw_convolver.c:598-622) as load_coeff applies it (bfconf.c:1958)
+    for (size_t i = 0; i < n; i++) {
+        const double v = e->rs == 4 ? (double)((const float *)cbufs)[i] : ((const double *)cbufs)[i];
+        if (!std::isfinite(v)) return fail(BFHIP_EINVAL, "NaN or Inf value among coefficients.");
+    }
+    const size_t bytes = n * e->rs;
+    if (bytes > e->taps_cap) {
+        if (e->d_taps) { { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; } (void)hipFree(e->d_taps); e->d_taps = nullptr; }
+        HIPCHK(hipMalloc(&e->d_taps, bytes));
+        e->taps_cap = bytes;
+    }
+    { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
+    HIPCHK(hipMemcpy(e->d_taps, cbufs, bytes, hipMemcpyHostToDevice));
+    Coeff c;
+    c.n_blocks = n_blocks;
+    if (hipMalloc(&c.d_H, (size_t)n_blocks * e->L * e->csize()) != hipSuccess)
+        return fail(BFHIP_ENOMEM, "out of device memory for coefficient set");
+    const dim3 grid((e->L + 255) / 256, n_blocks);
+    if (e->rs == 4)
+        hipLaunchKernelGGL(reorder_kernel<float>, grid, dim3(256), 0, e->stream, (const float *)e->d_taps, (c2<float> *)c.d_H, e->L, 1, (float *)nullptr);
+    else
+        hipLaunchKernelGGL(reorder_kernel<double>, grid, dim3(256), 0, e->stream, (const double *)e->d_taps, (c2<double> *)c.d_H, e->L, 1, (double *)nullptr);
+    HIPCHK(hipGetLastError());
+    { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
+    e->coeffs.push_back(c);
+    return (int)e->coeffs.size() - 1;
+}
+
+int bfhip_engine_read_coeff_processed(bfhip_engine *e, int coeff, void *cbufs) {
+    if (!e || !cbufs || coeff < 0 || coeff >= (int)e->coeffs.size()) return fail(BFHIP_EINVAL, "read_coeff_processed: bad argument");
+    HIPCHK(hipSetDevice(e->device));
+    const int nb = e->coeffs[coeff].n_blocks;
+    const size_t bytes = (size_t)nb * 2 * e->L * e->rs;
+    if (bytes > e->taps_cap) {
+        if (e->d_taps) { { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; } (void)hipFree(e->d_taps); e->d_taps = nullptr; }
+        HIPCHK(hipMalloc(&e->d_taps, bytes));
+        e->taps_cap = bytes;
+    }
+    const dim3 grid((e->L + 255) / 256, nb);
+    if (e->rs == 4)
+        hipLaunchKernelGGL(reorder_kernel<float>, grid, dim3(256), 0, e->stream, (const float *)nullptr, (c2<float> *)e->coeffs[coeff].d_H, e->L, 0, (float *)e->d_taps);
+    else
+        hipLaunchKernelGGL(reorder_kernel<double>, grid, dim3(256), 0, e->stream, (const double *)nullptr, (c2<double> *)e->coeffs[coeff].d_H, e->L, 0, (double *)e->d_taps);
+    HIPCHK(hipGetLastError());
+    { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
+    HIPCHK(hipMemcpy(cbufs, e->d_taps, bytes, hipMemcpyDeviceToHost));
+    return nb;
+}
+
 int bfhip_engine_update_coeff_block(bfhip_engine *e, int coeff, int block, const void *taps) {
     if (!e || coeff < 0 || coeff >= (int)e->coeffs.size() || block < 0 ||
         block >= e->coeffs[coeff].n_blocks || !taps)

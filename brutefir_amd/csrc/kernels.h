@@ -241,6 +241,26 @@ template <bool NT> struct Load16<double, NT> {
     }
 };
 
+// reference cbuf layout ("4 re / 4 im", Nyquist in slot 4; fftw_convfuns.h:25-43) <-> packed spectrum.
+// Pure permutation: what `format: "processed"` coefficient files and shared-memory coefficient
+// sets hold (bfconf.c:1924-1971) and what bfaccess->coeffs_data exposes (bfmod.h:139).
+template <typename T>
+__global__ void reorder_kernel(const T *__restrict__ q, c2<T> *__restrict__ packed, int L, int to_packed,
+                               T *__restrict__ q_out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int blk = blockIdx.y;
+    if (k >= L) return;
+    const size_t base = (size_t)blk * 2 * L;
+    const int qre = 8 * (k >> 2) + (k & 3), qim = qre + 4;
+    if (to_packed) {
+        packed[(size_t)blk * L + k] = mk<T>(q[base + qre], q[base + qim]);
+    } else {
+        const c2<T> v = packed[(size_t)blk * L + k];
+        q_out[base + qre] = v.x;
+        q_out[base + qim] = v.y;
+    }
+}
+
 // ------------------------------------------------------------------ K2: crossbar MAC
 
 // Z[o][k] (+)= sum over entries (ring, delay) and partitions p of

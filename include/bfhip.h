@@ -105,6 +105,14 @@ int bfhip_engine_add_coeff(bfhip_engine *e, const void *taps, int n_taps, double
                            int n_blocks);
 int bfhip_engine_add_coeff_dev(bfhip_engine *e, const void *taps_dev, int n_taps,
                                double scale, int n_blocks);
+/* load_coeff() for `format: "processed"` sets and shared-memory coefficient sets
+   (bfconf.c:1924-1971): n_blocks cbufs of 2L reals each, contiguous, in the reference's
+   internal frequency-domain layout (fftw_convfuns.h:25-43: groups of 4 re / 4 im, Nyquist in
+   slot 4, already divided by n_fft).  Checked like convolver_verify_cbuf. */
+int bfhip_engine_add_coeff_processed(bfhip_engine *e, const void *cbufs, int n_blocks);
+/* the inverse: a loaded set back in that layout (bfaccess->coeffs_data, debug dumps, writing
+   "processed" files); cbufs must hold n_blocks * 2L reals.  Returns n_blocks. */
+int bfhip_engine_read_coeff_processed(bfhip_engine *e, int coeff, void *cbufs);
 /* run-time replacement of one partition = convolver_runtime_coeffs2cbuf
    (fftw_convolver.c:575-596) as used by bflogic_eq (rendereq.h:87-91): L reals */
 int bfhip_engine_update_coeff_block(bfhip_engine *e, int coeff, int block, const void *taps);

@@ -337,3 +337,37 @@ def test_runtime_scale_and_delay_changes_keep_history_semantics(hip, rs):
         if b == 10:
             eng.set_scale(2, 0, 0, 1.5)
     _compare(hip, _spec(L, N, rs, 2, 2, filters, coeffs), 20, control=control)
+
+
+@pytest.mark.parametrize("rs", [4, 8])
+def test_processed_coefficient_format_round_trip(hip, rs):
+    """`format: "processed"` / shared-memory coefficient sets: cbufs in the reference's internal
+    layout go in (here produced by the oracle's coeffs2cbuf, which is the reference's layout),
+    filter like the same taps loaded the normal way, and come back out in that layout"""
+    L, N = 256, 4
+    dt = np.float32 if rs == 4 else np.float64
+    taps = _ir(90, L * 3).astype(dt)
+    oc = bo.Ctx(L, rs)
+    cbufs = np.stack([oc.coeffs2cbuf(taps[b * L:(b + 1) * L], 0.5) for b in range(3)])
+    e1 = hip.Engine(L, N, rs, 1, 1)
+    e2 = hip.Engine(L, N, rs, 1, 1)
+    for e in (e1, e2):
+        e.set_interleaved(0, "S24_4LE")
+        e.set_interleaved(1, FLOATFMT[rs])
+    c1 = e1.add_coeff_processed(cbufs)
+    c2 = e2.add_coeff(taps, 0.5, 3)
+    for e, c in ((e1, c1), (e2, c2)):
+        e.add_filter(in_ch=[0], out_ch=[0], coeff=c)
+        e.finalize()
+    tol = 3e-6 if rs == 4 else 1e-13
+    back = e2.read_coeff_processed(c2, 3)
+    assert np.abs(back - cbufs).max() <= tol * np.abs(cbufs).max() * 10
+    assert np.array_equal(e1.read_coeff_processed(c1, 3), cbufs)        # pure permutation
+    for blk in cases.raw_blocks(3, 8, L, 1, "S24_4LE"):
+        _, a = e1.block(blk)
+        _, b = e2.block(blk)
+        assert cases.rel_rms(cases.samples(a, FLOATFMT[rs]), cases.samples(b, FLOATFMT[rs])) <= TOL[rs]
+    bad = cbufs.copy()
+    bad[1, 7] = np.nan
+    with pytest.raises(hip.BfhipError, match="NaN or Inf"):
+        hip.Engine(L, N, rs, 1, 1).add_coeff_processed(bad)
