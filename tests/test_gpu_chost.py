@@ -1,0 +1,49 @@
+"""GPU: the C ABI driven from plain C (examples/bffilter.c, gcc, no Python in the data path):
+file -> file filtering like `brutefir` with bfio_file on both sides; output compared with the
+oracle run on the same file."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import bforacle as bo
+import cases
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_host_file_to_file(hip, tmp_path):
+    exe = os.path.join(ROOT, "examples", "bffilter")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "bffilter.c"), "-o", exe,
+                           "-L" + os.path.join(ROOT, "brutefir_amd"), "-lbfhip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "brutefir_amd")])
+    L, N, I, O = 512, 4, 2, 3
+    irs = np.stack([cases.make_ir(np.random.default_rng(100 + k), L * N, I) for k in range(O * I)])
+    irs.astype(np.float32).tofile(tmp_path / "coeffs.f32")
+    nblk = 9
+    blocks = cases.raw_blocks(42, nblk, L, I, "S16_LE", amplitude=0.2)
+    raw = np.concatenate(blocks)[:nblk * L - 100]                   # a ragged last block
+    raw.tofile(tmp_path / "in.raw")
+    r = subprocess.run([exe, str(L), str(N), str(I), str(O), "S16_LE", "S24_4LE",
+                        str(tmp_path / "coeffs.f32"), str(tmp_path / "in.raw"),
+                        str(tmp_path / "out.raw")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "%d blocks" % nblk in r.stderr
+    got = np.fromfile(tmp_path / "out.raw", np.int32).reshape(-1, O)
+    assert got.shape[0] == raw.shape[0]                             # as many frames out as in
+    oe = bo.Engine(L, N, 4, I, O)
+    oe.set_interleaved(0, "S16_LE")
+    oe.set_interleaved(1, "S24_4LE")
+    for o in range(O):
+        for i in range(I):
+            oe.add_filter(in_ch=[i], out_ch=[o], coeff=oe.add_coeff(irs[o * I + i].astype(np.float32)))
+    padded = np.concatenate([raw, np.zeros((100, I), np.int16)])
+    want = []
+    for b in range(nblk):
+        _, out = oe.block(padded[b * L:(b + 1) * L])
+        want.append(out.view(np.int32).reshape(L, O))
+    want = np.concatenate(want)[:raw.shape[0]]
+    assert np.abs(got.astype(np.int64) - want).max() <= 1
