@@ -126,3 +126,52 @@ def test_identity_crossbar_roundtrip_24bit(hip):
     for c in range(O):
         of = e.overflow(c)
         assert of.n_overflows == 0 and of.intlargest > 0
+
+
+def test_config_d_shape_256_one_to_one_filters(hip):
+    """BASELINE configs[3] shape on one GPU (massive_config style): 256 one-to-one filters of
+    131072 taps (8192 x 16); 6 of the 256 channels recomputed by the oracle"""
+    Ld, Nd, C = 8192, 16, 256
+    ge = hip.Engine(Ld, Nd, 4, C, C)
+    ge.set_interleaved(0, FMT)
+    ge.set_interleaved(1, "FLOAT_LE")
+    spot = [0, 7, 100, 101, 254, 255]
+    irs = {}
+    for c in range(C):
+        h = cases.make_ir(np.random.default_rng(9000 + c), Ld * Nd, 1).astype(np.float32)
+        if c in spot:
+            irs[c] = h
+        ge.add_filter(in_ch=[c], out_ch=[c], coeff=ge.add_coeff(h))
+    ge.finalize()
+    oe = bo.Engine(Ld, Nd, 4, len(spot), len(spot))
+    oe.set_interleaved(0, FMT)
+    oe.set_interleaved(1, "FLOAT_LE")
+    for k, c in enumerate(spot):
+        oe.add_filter(in_ch=[k], out_ch=[k], coeff=oe.add_coeff(irs[c]))
+    for b, blk in enumerate(cases.raw_blocks(31, Nd + 3, Ld, C, FMT)):
+        gs, g = ge.block(blk)
+        os_, o = oe.block(np.ascontiguousarray(blk[:, spot]))
+        assert gs == os_ == 0
+        if b >= Nd:
+            gy = np.frombuffer(g.tobytes(), np.float32).reshape(Ld, C)[:, spot]
+            oy = np.frombuffer(o.tobytes(), np.float32).reshape(Ld, len(spot))
+            assert cases.rel_rms(gy, oy) <= 1e-5, b
+
+
+def test_config_e_shape_float64_million_taps(hip):
+    """BASELINE configs[4] as uniform partitions (the reference only has uniform ones,
+    SURVEY 0.2): 2-in/2-out, 1048576 taps = 8192 x 128, float64, <= 1e-12 relative RMS"""
+    Le, Ne = 8192, 128
+    spec = dict(L=Le, N=Ne, rs=8, n_in=2, n_out=2, infmt="FLOAT64_LE", outfmt="FLOAT64_LE",
+                coeffs=[(cases.make_ir(np.random.default_rng(700 + k), Le * Ne, 2), 1.0, 0) for k in range(4)],
+                filters=[dict(in_ch=[i], out_ch=[o], coeff=o * 2 + i) for o in range(2) for i in range(2)])
+    ge, oe = cases.build(hip.Engine, spec), cases.build(bo.Engine, spec)
+    blocks = cases.raw_blocks(8, 4, Le, 2, "FLOAT64_LE")
+    for b in range(Ne + 3):
+        blk = blocks[b % 4]
+        gs, g = ge.block(blk)
+        os_, o = oe.block(blk)
+        assert gs == os_ == 0
+        if b in (0, 1, Ne - 1, Ne, Ne + 1, Ne + 2):
+            err = cases.rel_rms(np.frombuffer(g.tobytes(), np.float64), np.frombuffer(o.tobytes(), np.float64))
+            assert err <= 1e-12, (b, err)
