@@ -89,7 +89,7 @@ struct bfhip_engine {
     // FFT / requantiser of block t-1 run on their own streams beside the HBM-bound MAC of
     // block t, the way the reference overlaps its input, filter and output processes
     // (bfrun.c:2312-2616).  Needs one spare ring slot (R = N + 1) and two Zp buffers.
-    bool pipelined = false;            // opt-in (BFHIP_OVERLAP=1): measured slower on MI355X, see DESIGN.md
+    bool pipelined = false;            // decided at finalize (or BFHIP_OVERLAP=0/1)
     hipStream_t s_in = nullptr, s_out = nullptr;
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_mac[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
     int R = 0;                         // depth of the input rings
@@ -193,8 +193,8 @@ template <typename K> hipError_t allow_lds(K kernel, size_t bytes) {
 
 template <typename T, int LOG2L>
 void launch_fft_in(bfhip_engine *e, const uint8_t *raw, int slot, hipError_t *err) {
-    constexpr int NT = fft_threads(LOG2L);
-    const size_t lds = sizeof(c2<T>) << LOG2L;
+    constexpr int NT = fft_threads<T>(LOG2L);
+    const size_t lds = lds_fft_bytes(LOG2L, sizeof(c2<T>));
     auto k = fft_in_kernel<T, LOG2L>;
     *err = allow_lds(k, lds);
     if (*err != hipSuccess) return;
@@ -206,8 +206,8 @@ void launch_fft_in(bfhip_engine *e, const uint8_t *raw, int slot, hipError_t *er
 template <typename T, int LOG2L>
 void launch_coeff_prep(bfhip_engine *e, const void *taps, int n_taps, double scale, void *H,
                        int n_blocks, hipError_t *err) {
-    constexpr int NT = fft_threads(LOG2L);
-    const size_t lds = sizeof(c2<T>) << LOG2L;
+    constexpr int NT = fft_threads<T>(LOG2L);
+    const size_t lds = lds_fft_bytes(LOG2L, sizeof(c2<T>));
     auto k = coeff_prep_kernel<T, LOG2L>;
     *err = allow_lds(k, lds);
     if (*err != hipSuccess) return;
@@ -219,8 +219,8 @@ void launch_coeff_prep(bfhip_engine *e, const void *taps, int n_taps, double sca
 template <typename T, int LOG2L>
 void launch_ifft_out(bfhip_engine *e, const void *Zp, size_t chunk_stride, int n_chunks,
                      int first, int count, uint8_t *raw, hipError_t *err) {
-    constexpr int NT = fft_threads(LOG2L);
-    const size_t lds = sizeof(c2<T>) << LOG2L;
+    constexpr int NT = fft_threads<T>(LOG2L);
+    const size_t lds = lds_fft_bytes(LOG2L, sizeof(c2<T>));
     auto k = ifft_out_kernel<T, LOG2L>;
     *err = allow_lds(k, lds);
     if (*err != hipSuccess) return;
@@ -277,8 +277,8 @@ void launch_sum(bfhip_engine *e, const void *Zp, void *Z, hipError_t *err) {
 
 template <typename T, int LOG2L>
 void launch_levels(bfhip_engine *e, hipError_t *err) {
-    constexpr int NT = fft_threads(LOG2L);
-    const size_t lds = sizeof(c2<T>) << LOG2L;
+    constexpr int NT = fft_threads<T>(LOG2L);
+    const size_t lds = lds_fft_bytes(LOG2L, sizeof(c2<T>));
     auto kf = ring_fill_kernel<T, LOG2L>;
     auto kx = crossfade_kernel<T, LOG2L>;
     const unsigned long long age64 = std::min<unsigned long long>(e->blocks_done + 1, (unsigned long long)e->N);
@@ -1033,7 +1033,19 @@ int bfhip_engine_finalize(bfhip_engine *e) {
     HIPCHK(hipSetDevice(e->device));
     const size_t L = e->L;
     const size_t prev_b = (size_t)e->n_ch[0] * L * e->rs;
-    if (getenv("BFHIP_OVERLAP")) e->pipelined = true;
+    // Run the FFT kernels of neighbouring blocks beside the MAC?  Pays when the MAC is short
+    // (small crossbars: config B 84 -> 58 us per block) and costs when it streams for a
+    // millisecond (config C 1.40 -> 1.77 ms): decide from the coefficient bytes per block.
+    {
+        double bytes = 0;
+        for (auto &f : e->filters) {
+            if (f.coeff < 0) continue;
+            const int d = clamp_delay(e, f.delayblocks);
+            bytes += (double)cblocks_of(e, f.coeff, d) * e->L * e->csize() * std::max<size_t>(1, f.out_ch.size());
+        }
+        e->pipelined = bytes / 6.4e12 < 100e-6;
+        if (const char *env = getenv("BFHIP_OVERLAP")) e->pipelined = atoi(env) != 0;
+    }
     e->R = e->pipelined ? e->N + 1 : e->N;
     const size_t ring_b = (size_t)e->n_ch[0] * e->R * L * e->csize();
     if (hipMalloc(&e->d_prev, prev_b) != hipSuccess || hipMalloc(&e->d_ring, ring_b) != hipSuccess)

@@ -108,25 +108,25 @@ __global__ void k_scale_all(T *b, T s, int n) {
 
 // FFTW R2HC of 2L reals (in may equal out)
 template <typename T, int LOG2L>
-__global__ __launch_bounds__(fft_threads(LOG2L)) void
+__global__ __launch_bounds__(fft_threads<T>(LOG2L)) void
 k_r2hc(const T *in, T *out, const c2<T> *__restrict__ tw) {
-    constexpr int L = 1 << LOG2L, NT = fft_threads(LOG2L);
+    constexpr int L = 1 << LOG2L, NT = fft_threads<T>(LOG2L);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    c2<T> *s = reinterpret_cast<c2<T> *>(smem);
+    LdsArr<T> s{reinterpret_cast<c2<T> *>(smem)};
     const int tid = threadIdx.x;
+    TwRegs<T, LOG2L, NT> twr;
+    twr.prefetch(tw);
     for (int n = tid; n < L; n += NT) s[n] = mk<T>(in[2 * n], in[2 * n + 1]);
     __syncthreads();
-    lds_fft<T, LOG2L, NT, false>(s, tw);
+    lds_fft<T, LOG2L, NT, false>(s, twr);
     for (int k = tid; k <= L / 2; k += NT) {
         if (k == 0) {
-            out[0] = s[0].x + s[0].y;
-            out[L] = s[0].x - s[0].y;
+            const c2<T> z = s[0];
+            out[0] = z.x + z.y;
+            out[L] = z.x - z.y;
         } else {
-            const c2<T> a = s[k], b = conj(s[L - k]);
-            const c2<T> e = mk<T>((T)0.5 * (a.x + b.x), (T)0.5 * (a.y + b.y));
-            const c2<T> d = mk<T>((T)0.5 * (a.x - b.x), (T)0.5 * (a.y - b.y));
-            const c2<T> wo = cmul(mk<T>(d.y, -d.x), tw[k]);
-            const c2<T> x = e + wo, y = conj(e - wo);
+            c2<T> x, y;
+            untangle(s[k], conj(s[L - k]), tw[k], x, y);
             out[k] = x.x; out[2 * L - k] = x.y;
             if (k != L - k) { out[L - k] = y.x; out[L + k] = y.y; }
         }
@@ -135,27 +135,29 @@ k_r2hc(const T *in, T *out, const c2<T> *__restrict__ tw) {
 
 // FFTW HC2R, unnormalised (in may equal out)
 template <typename T, int LOG2L>
-__global__ __launch_bounds__(fft_threads(LOG2L)) void
+__global__ __launch_bounds__(fft_threads<T>(LOG2L)) void
 k_hc2r(const T *in, T *out, const c2<T> *__restrict__ tw) {
-    constexpr int L = 1 << LOG2L, NT = fft_threads(LOG2L);
+    constexpr int L = 1 << LOG2L, NT = fft_threads<T>(LOG2L);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    c2<T> *s = reinterpret_cast<c2<T> *>(smem);
+    LdsArr<T> s{reinterpret_cast<c2<T> *>(smem)};
     const int tid = threadIdx.x;
+    TwRegs<T, LOG2L, NT> twr;
+    twr.prefetch(tw);
     for (int k = tid; k <= L / 2; k += NT) {
         if (k == 0) {
             s[0] = mk<T>(in[0] + in[L], in[0] - in[L]);
         } else {
             const c2<T> a = mk<T>(in[k], in[2 * L - k]);
             const c2<T> b = (k == L - k) ? conj(a) : mk<T>(in[L - k], -in[L + k]);
-            const c2<T> e = a + b, d = a - b;
-            const c2<T> o = cmul(d, conj(tw[k]));
-            s[k] = mk<T>(e.x - o.y, e.y + o.x);
-            if (k != L - k) s[L - k] = mk<T>(e.x + o.y, -e.y + o.x);
+            c2<T> zk, zlk;
+            tangle(a, b, tw[k], zk, zlk);
+            s[k] = zk;
+            if (k != L - k) s[L - k] = zlk;
         }
     }
     __syncthreads();
-    lds_fft<T, LOG2L, NT, true>(s, tw);
-    for (int n = tid; n < L; n += NT) { out[2 * n] = s[n].x; out[2 * n + 1] = s[n].y; }
+    lds_fft<T, LOG2L, NT, true>(s, twr);
+    for (int n = tid; n < L; n += NT) { const c2<T> z = s[n]; out[2 * n] = z.x; out[2 * n + 1] = z.y; }
 }
 
 // the ramp of convolver_crossfade_inplace, float-branch arithmetic (fftw_convolver.c:349-355)
@@ -405,8 +407,8 @@ bool down(void *dst, const void *src, size_t n) {
 
 template <typename T, int LOG2>
 void fft_launch(bool inverse, const void *in, void *out) {
-    constexpr int NT = fft_threads(LOG2);
-    const size_t lds = sizeof(c2<T>) << LOG2;
+    constexpr int NT = fft_threads<T>(LOG2);
+    const size_t lds = lds_fft_bytes(LOG2, sizeof(c2<T>));
     const c2<T> *tw = (const c2<T> *)twiddles(LOG2);
     if (inverse) {
         auto k = k_hc2r<T, LOG2>;

@@ -1,8 +1,8 @@
 // fft_lds.h -- in-LDS Stockham FFT for one workgroup (gfx950, wave64).
 //
 // A complex FFT of L = 2^LOG2L points lives entirely in LDS (L <= 8192 complex:
-// 64 KiB f32 / 128 KiB f64 of the CU's 160 KiB) and is transformed in place by
-// radix-8 passes (plus one radix-4 or radix-2 tail pass).  Every pass is the
+// 68 KiB f32 / 136 KiB f64 of the CU's 160 KiB, padding included) and is transformed in
+// place by radix-8 passes (plus one radix-4 or radix-2 tail pass).  Every pass is the
 // autosort form
 //     u[r]  = s[j + r*T] * w^(r*k),   T = L/R, k = j mod Ns, w = exp(-+2 pi i/(Ns*R))
 //     v     = DFT_R(u)
@@ -12,9 +12,17 @@
 // makes the in-place update legal; butterfly counts per thread are compile-time
 // so nothing is runtime-indexed (no scratch).
 //
+// Latency matters more than throughput here (one workgroup per channel, and on 8 GPUs
+// only 8 workgroups per launch), so:
+//  * the twiddles a thread needs for ALL passes depend only on its thread id: they are
+//    fetched into registers up front (TwRegs::prefetch) while the kernel is still loading
+//    its input, instead of one dependent L2/HBM round trip per pass; per radix-8 butterfly
+//    only w, w^2, w^4 are fetched and w^3, w^5, w^6, w^7 are products;
+//  * the LDS array is padded by one element per 16 (LdsArr) so that the stride-R stores of
+//    the first pass do not all hit the same banks.
+//
 // The real transforms the convolver needs (FFTW R2HC / HC2R of 2L reals,
-// fftw_convolver.c:113-119) are built on it with the usual even/odd packing; see
-// untangle_forward / tangle_inverse in kernels.h.
+// fftw_convolver.c:113-119) are built on it with the usual even/odd packing.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -29,6 +37,13 @@ template <typename T> __device__ __forceinline__ c2<T> cmul(c2<T> a, c2<T> b) { 
 template <typename T> __device__ __forceinline__ c2<T> conj(c2<T> a) { return mk<T>(a.x, -a.y); }
 // multiply by -i (forward) / +i (inverse)
 template <typename T, bool INV> __device__ __forceinline__ c2<T> rot90(c2<T> a) { return INV ? mk<T>(-a.y, a.x) : mk<T>(a.y, -a.x); }
+
+// LDS array with one pad element per 16: element i lives at i + (i >> 4)
+template <typename T> struct LdsArr {
+    c2<T> *p;
+    __device__ __forceinline__ c2<T> &operator[](int i) const { return p[i + (i >> 4)]; }
+};
+constexpr size_t lds_fft_bytes(int log2l, size_t elem) { return (((size_t)1 << log2l) + (((size_t)1 << log2l) >> 4) + 1) * elem; }
 
 template <typename T, bool INV> __device__ __forceinline__ void dft2(c2<T> *u) {
     c2<T> a = u[0] + u[1], b = u[0] - u[1];
@@ -63,12 +78,53 @@ template <typename T, bool INV, int R> __device__ __forceinline__ void dftR(c2<T
     else dft2<T, INV>(u);
 }
 
-// one Stockham pass; tw = exp(-2 pi i m / (2L)), m in [0, 2L), in global memory
-template <typename T, int LOG2L, int NT, bool INV, int LOG2NS, int LOG2R>
-__device__ __forceinline__ void fft_pass(c2<T> *s, const c2<T> *__restrict__ tw) {
+// ---- pass geometry, shared by the prefetch and the passes themselves
+constexpr int pass_log2r(int log2l, int log2ns) { return (log2l - log2ns >= 3) ? 3 : (log2l - log2ns); }
+constexpr int pass_b(int log2l, int nt, int log2ns) {       // butterflies per thread
+    return (((1 << log2l) >> pass_log2r(log2l, log2ns)) + nt - 1) / nt;
+}
+constexpr int pass_ntw(int log2l, int log2ns) {             // fetched twiddles per butterfly
+    return log2ns == 0 ? 0 : pass_log2r(log2l, log2ns);    // w, w^2, w^4 -> log2(R) of them
+}
+constexpr int tw_total(int log2l, int nt, int log2ns) {
+    return log2ns >= log2l ? 0
+        : pass_b(log2l, nt, log2ns) * pass_ntw(log2l, log2ns) + tw_total(log2l, nt, log2ns + pass_log2r(log2l, log2ns));
+}
+
+// The twiddles of every pass for this thread, in registers.
+// tw = exp(-2 pi i m / (2L)), m in [0, 2L), in global memory.
+template <typename T, int LOG2L, int NT> struct TwRegs {
+    static constexpr int N = tw_total(LOG2L, NT, 0) > 0 ? tw_total(LOG2L, NT, 0) : 1;
+    c2<T> r[N];
+
+    template <int LOG2NS, int OFF>
+    __device__ __forceinline__ void fetch_from(const c2<T> *__restrict__ tw) {
+        if constexpr (LOG2NS < LOG2L) {
+            constexpr int LOG2R = pass_log2r(LOG2L, LOG2NS);
+            constexpr int L = 1 << LOG2L, R = 1 << LOG2R, Ns = 1 << LOG2NS, TT = L / R;
+            constexpr int B = pass_b(LOG2L, NT, LOG2NS), NTW = pass_ntw(LOG2L, LOG2NS);
+            constexpr int TWSTEP = (2 * L) / (Ns * R);
+            if constexpr (NTW > 0) {
+#pragma unroll
+                for (int b = 0; b < B; b++) {
+                    const int j = threadIdx.x + b * NT;
+                    const int k = (TT % NT == 0 || j < TT) ? (j & (Ns - 1)) : 0;
+#pragma unroll
+                    for (int i = 0; i < NTW; i++) r[OFF + b * NTW + i] = tw[(k << i) * TWSTEP];
+                }
+            }
+            fetch_from<LOG2NS + LOG2R, OFF + B * NTW>(tw);
+        }
+    }
+    __device__ __forceinline__ void prefetch(const c2<T> *__restrict__ tw) { fetch_from<0, 0>(tw); }
+};
+
+// one Stockham pass on the padded LDS array with prefetched twiddles
+template <typename T, int LOG2L, int NT, bool INV, int LOG2NS, int OFF>
+__device__ __forceinline__ void fft_pass(LdsArr<T> s, const TwRegs<T, LOG2L, NT> &tw) {
+    constexpr int LOG2R = pass_log2r(LOG2L, LOG2NS);
     constexpr int L = 1 << LOG2L, R = 1 << LOG2R, Ns = 1 << LOG2NS, TT = L / R;
-    constexpr int B = (TT + NT - 1) / NT;
-    constexpr int TWSTEP = (2 * L) / (Ns * R);
+    constexpr int B = pass_b(LOG2L, NT, LOG2NS), NTW = pass_ntw(LOG2L, LOG2NS);
     c2<T> u[B][R];
     const int tid = threadIdx.x;
 #pragma unroll
@@ -77,14 +133,22 @@ __device__ __forceinline__ void fft_pass(c2<T> *s, const c2<T> *__restrict__ tw)
         if (TT % NT == 0 || j < TT) {
 #pragma unroll
             for (int r = 0; r < R; r++) u[b][r] = s[j + r * TT];
-            if constexpr (LOG2NS > 0) {
-                const int k = j & (Ns - 1);
-#pragma unroll
-                for (int r = 1; r < R; r++) {
-                    c2<T> w = tw[r * k * TWSTEP];
-                    if (INV) w.y = -w.y;
-                    u[b][r] = cmul(u[b][r], w);
+            if constexpr (NTW > 0) {
+                c2<T> w[R];
+                w[1] = tw.r[OFF + b * NTW];
+                if (INV) w[1].y = -w[1].y;
+                if constexpr (R >= 4) {
+                    w[2] = tw.r[OFF + b * NTW + 1];
+                    if (INV) w[2].y = -w[2].y;
+                    w[3] = cmul(w[1], w[2]);
                 }
+                if constexpr (R == 8) {
+                    w[4] = tw.r[OFF + b * NTW + 2];
+                    if (INV) w[4].y = -w[4].y;
+                    w[5] = cmul(w[4], w[1]); w[6] = cmul(w[4], w[2]); w[7] = cmul(w[4], w[3]);
+                }
+#pragma unroll
+                for (int r = 1; r < R; r++) u[b][r] = cmul(u[b][r], w[r]);
             }
             dftR<T, INV, R>(u[b]);
         }
@@ -103,27 +167,27 @@ __device__ __forceinline__ void fft_pass(c2<T> *s, const c2<T> *__restrict__ tw)
     __syncthreads();
 }
 
-template <typename T, int LOG2L, int NT, bool INV, int LOG2NS>
-__device__ __forceinline__ void fft_passes(c2<T> *s, const c2<T> *__restrict__ tw) {
-    constexpr int REM = LOG2L - LOG2NS;
-    if constexpr (REM >= 3) {
-        fft_pass<T, LOG2L, NT, INV, LOG2NS, 3>(s, tw);
-        fft_passes<T, LOG2L, NT, INV, LOG2NS + 3>(s, tw);
-    } else if constexpr (REM == 2) {
-        fft_pass<T, LOG2L, NT, INV, LOG2NS, 2>(s, tw);
-    } else if constexpr (REM == 1) {
-        fft_pass<T, LOG2L, NT, INV, LOG2NS, 1>(s, tw);
+template <typename T, int LOG2L, int NT, bool INV, int LOG2NS, int OFF>
+__device__ __forceinline__ void fft_passes(LdsArr<T> s, const TwRegs<T, LOG2L, NT> &tw) {
+    if constexpr (LOG2NS < LOG2L) {
+        constexpr int LOG2R = pass_log2r(LOG2L, LOG2NS);
+        fft_pass<T, LOG2L, NT, INV, LOG2NS, OFF>(s, tw);
+        fft_passes<T, LOG2L, NT, INV, LOG2NS + LOG2R, OFF + pass_b(LOG2L, NT, LOG2NS) * pass_ntw(LOG2L, LOG2NS)>(s, tw);
     }
 }
 
-// Complex FFT of the L values in s (LDS), in place, natural order in and out.
+// Complex FFT of the L values in s (padded LDS array), in place, natural order in and out.
 // The caller has synchronised after filling s; on return all threads see the result.
 template <typename T, int LOG2L, int NT, bool INV>
-__device__ __forceinline__ void lds_fft(c2<T> *s, const c2<T> *__restrict__ tw) {
-    fft_passes<T, LOG2L, NT, INV, 0>(s, tw);
+__device__ __forceinline__ void lds_fft(LdsArr<T> s, const TwRegs<T, LOG2L, NT> &tw) {
+    fft_passes<T, LOG2L, NT, INV, 0, 0>(s, tw);
 }
 
-// threads per workgroup used for a transform of 2^LOG2L complex points
-constexpr int fft_threads(int log2l) { return (1 << log2l) / 8 < 64 ? 64 : ((1 << log2l) / 8 > 1024 ? 1024 : (1 << log2l) / 8); }
+// threads per workgroup used for a transform of 2^LOG2L complex points: one radix-8 butterfly
+// per thread, at most 1024 threads (float) / 512 (double: twice the registers per value, and
+// 1024 threads would cap the kernel at 128 VGPRs)
+template <typename T> constexpr int fft_threads(int log2l) {
+    return (1 << log2l) / 8 < 64 ? 64 : ((1 << log2l) / 8 > (sizeof(T) == 8 ? 512 : 1024) ? (sizeof(T) == 8 ? 512 : 1024) : (1 << log2l) / 8);
+}
 
 }  // namespace bfhip

@@ -124,52 +124,92 @@ __device__ __forceinline__ void store_raw_bytes(uint8_t *p, const uint8_t *t, in
 
 // ------------------------------------------------------------------ K1: raw -> spectrum
 
+// helpers shared by the kernels that run the in-LDS real FFTs --------------------------
+
+// bins this thread untangles: k = 1 + tid + i*NT (i < QU) covers 1..L/2; k = 0 is thread 0's
+template <typename T, int LOG2L> struct UT {
+    static constexpr int L = 1 << LOG2L, NT = fft_threads<T>(LOG2L);
+    static constexpr int QU = (L / 2 + NT - 1) / NT;     // bins (pairs k, L-k) per thread
+    static constexpr int QP = (L / 2 + NT - 1) / NT;     // sample pairs per thread and half
+};
+
+// forward untangle of bin pair (k, L-k): X[k] = E + w^k O, X[L-k] = conj(E - w^k O)
+template <typename T>
+__device__ __forceinline__ void untangle(c2<T> a, c2<T> bconj, c2<T> w, c2<T> &xk, c2<T> &xlk) {
+    const c2<T> e = mk<T>((T)0.5 * (a.x + bconj.x), (T)0.5 * (a.y + bconj.y));
+    const c2<T> d = mk<T>((T)0.5 * (a.x - bconj.x), (T)0.5 * (a.y - bconj.y));
+    const c2<T> wo = cmul(mk<T>(d.y, -d.x), w);           // (d / i) * w^k
+    xk = e + wo;
+    xlk = conj(e - wo);
+}
+
+// inverse pre-pass of bin pair: Z'[k] = 2E + i 2O, Z'[L-k] = conj(2E) + i conj(2O)
+template <typename T>
+__device__ __forceinline__ void tangle(c2<T> a, c2<T> bconj, c2<T> w, c2<T> &zk, c2<T> &zlk) {
+    const c2<T> e = a + bconj, d = a - bconj;
+    const c2<T> o = cmul(d, conj(w));
+    zk = mk<T>(e.x - o.y, e.y + o.x);
+    zlk = mk<T>(e.x + o.y, -e.y + o.x);
+}
+
 // One workgroup per input channel.  Window = [previous L samples | new L samples]
 // (fftw_convolver.c:181-193); z[n] = x[2n] + i x[2n+1]; complex FFT; untangle; write the
-// packed spectrum into ring slot `slot` of that channel.
+// packed spectrum into ring slot `slot` of that channel.  All global loads (twiddles,
+// previous block, raw samples) are issued before anything waits on them.
 template <typename T, int LOG2L>
-__global__ __launch_bounds__(fft_threads(LOG2L)) void
+__global__ __launch_bounds__(fft_threads<T>(LOG2L)) void
 fft_in_kernel(const uint8_t *__restrict__ raw, const DevFormat *__restrict__ fmt,
               T *__restrict__ prev,            // [n_in][L] last block's samples
               c2<T> *__restrict__ ring,        // [n_in][R][L]
               const c2<T> *__restrict__ tw, int R, int slot) {
-    constexpr int L = 1 << LOG2L, NT = fft_threads(LOG2L);
+    constexpr int L = 1 << LOG2L, NT = fft_threads<T>(LOG2L);
+    constexpr int QP = UT<T, LOG2L>::QP, QU = UT<T, LOG2L>::QU;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    c2<T> *s = reinterpret_cast<c2<T> *>(smem);
+    LdsArr<T> s{reinterpret_cast<c2<T> *>(smem)};
     const int ch = blockIdx.x, tid = threadIdx.x;
     const DevFormat f = fmt[ch];
-    T *pv = prev + (size_t)ch * L;
+    c2<T> *pv = reinterpret_cast<c2<T> *>(prev + (size_t)ch * L);
     const uint8_t *base = raw + f.byte_offset;
     const size_t stride = (size_t)f.sample_spacing * f.bytes;
 
-    // first half of z from the previous block, second half from the new samples
-    for (int n = tid; n < L / 2; n += NT) {
-        s[n] = mk<T>(pv[2 * n], pv[2 * n + 1]);
+    TwRegs<T, LOG2L, NT> twr;
+    twr.prefetch(tw);
+    c2<T> uw[QU];
+#pragma unroll
+    for (int i = 0; i < QU; i++) { const int k = 1 + tid + i * NT; uw[i] = tw[k <= L / 2 ? k : 0]; }
+
+    c2<T> old[QP], cur[QP];
+#pragma unroll
+    for (int i = 0; i < QP; i++) {
+        const int n = tid + i * NT;
+        if (L / 2 % NT == 0 || n < L / 2) {
+            old[i] = pv[n];
+            cur[i] = mk<T>(load_raw<T>(base + (size_t)(2 * n) * stride, f),
+                           load_raw<T>(base + (size_t)(2 * n + 1) * stride, f));
+        }
     }
-    __syncthreads();   // all reads of prev done before it is overwritten
-    for (int n = tid; n < L / 2; n += NT) {
-        const T a = load_raw<T>(base + (size_t)(2 * n) * stride, f);
-        const T b = load_raw<T>(base + (size_t)(2 * n + 1) * stride, f);
-        s[L / 2 + n] = mk<T>(a, b);
-        pv[2 * n] = a;
-        pv[2 * n + 1] = b;
+#pragma unroll
+    for (int i = 0; i < QP; i++) {
+        const int n = tid + i * NT;
+        if (L / 2 % NT == 0 || n < L / 2) {
+            s[n] = old[i];
+            s[L / 2 + n] = cur[i];
+            pv[n] = cur[i];                      // same thread read it above: no hazard
+        }
     }
     __syncthreads();
-    lds_fft<T, LOG2L, NT, false>(s, tw);
+    lds_fft<T, LOG2L, NT, false>(s, twr);
 
-    // X[k] = E[k] + w^k O[k], X[L-k] = conj(E[k] - w^k O[k]),  w = exp(-i pi / L)
     c2<T> *out = ring + ((size_t)ch * R + slot) * L;
-    for (int k = tid; k <= L / 2; k += NT) {
-        if (k == 0) {
-            out[0] = mk<T>(s[0].x + s[0].y, s[0].x - s[0].y);
-        } else {
-            const c2<T> a = s[k], b = conj(s[L - k]);
-            const c2<T> e = mk<T>((T)0.5 * (a.x + b.x), (T)0.5 * (a.y + b.y));
-            const c2<T> d = mk<T>((T)0.5 * (a.x - b.x), (T)0.5 * (a.y - b.y));
-            const c2<T> o = mk<T>(d.y, -d.x);           // d / i
-            const c2<T> wo = cmul(o, tw[k]);
-            out[k] = e + wo;
-            if (k != L - k) out[L - k] = conj(e - wo);
+    if (tid == 0) out[0] = mk<T>(s[0].x + s[0].y, s[0].x - s[0].y);
+#pragma unroll
+    for (int i = 0; i < QU; i++) {
+        const int k = 1 + tid + i * NT;
+        if (k <= L / 2) {
+            c2<T> xk, xlk;
+            untangle(s[k], conj(s[L - k]), uw[i], xk, xlk);
+            out[k] = xk;
+            if (k != L - k) out[L - k] = xlk;
         }
     }
 }
@@ -179,14 +219,20 @@ fft_in_kernel(const uint8_t *__restrict__ raw, const DevFormat *__restrict__ fmt
 // One workgroup per partition: [0..L) zero, [L..2L) = taps * scale, real FFT, * 1/n_fft.
 // (fftw_convolver.c:535-569).  bad[0] is set if a scaled tap is not finite.
 template <typename T, int LOG2L>
-__global__ __launch_bounds__(fft_threads(LOG2L)) void
+__global__ __launch_bounds__(fft_threads<T>(LOG2L)) void
 coeff_prep_kernel(const T *__restrict__ taps, int n_taps, T scale, c2<T> *__restrict__ H,
                   const c2<T> *__restrict__ tw, int *__restrict__ bad) {
-    constexpr int L = 1 << LOG2L, NT = fft_threads(LOG2L);
+    constexpr int L = 1 << LOG2L, NT = fft_threads<T>(LOG2L);
+    constexpr int QU = UT<T, LOG2L>::QU;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    c2<T> *s = reinterpret_cast<c2<T> *>(smem);
+    LdsArr<T> s{reinterpret_cast<c2<T> *>(smem)};
     const int part = blockIdx.x, tid = threadIdx.x;
     const int first = part * L;
+    TwRegs<T, LOG2L, NT> twr;
+    twr.prefetch(tw);
+    c2<T> uw[QU];
+#pragma unroll
+    for (int i = 0; i < QU; i++) { const int k = 1 + tid + i * NT; uw[i] = tw[k <= L / 2 ? k : 0]; }
     int notfinite = 0;
     for (int n = tid; n < L / 2; n += NT) {
         s[n] = mk<T>((T)0, (T)0);
@@ -198,21 +244,18 @@ coeff_prep_kernel(const T *__restrict__ taps, int n_taps, T scale, c2<T> *__rest
     }
     if (notfinite) atomicOr(bad, 1);
     __syncthreads();
-    lds_fft<T, LOG2L, NT, false>(s, tw);
+    lds_fft<T, LOG2L, NT, false>(s, twr);
     const T inv = (T)1.0 / (T)(2 * L);
     c2<T> *out = H + (size_t)part * L;
-    for (int k = tid; k <= L / 2; k += NT) {
-        if (k == 0) {
-            out[0] = mk<T>((s[0].x + s[0].y) * inv, (s[0].x - s[0].y) * inv);
-        } else {
-            const c2<T> a = s[k], b = conj(s[L - k]);
-            const c2<T> e = mk<T>((T)0.5 * (a.x + b.x), (T)0.5 * (a.y + b.y));
-            const c2<T> d = mk<T>((T)0.5 * (a.x - b.x), (T)0.5 * (a.y - b.y));
-            const c2<T> o = mk<T>(d.y, -d.x);
-            const c2<T> wo = cmul(o, tw[k]);
-            const c2<T> x = e + wo, y = conj(e - wo);
-            out[k] = mk<T>(x.x * inv, x.y * inv);
-            if (k != L - k) out[L - k] = mk<T>(y.x * inv, y.y * inv);
+    if (tid == 0) out[0] = mk<T>((s[0].x + s[0].y) * inv, (s[0].x - s[0].y) * inv);
+#pragma unroll
+    for (int i = 0; i < QU; i++) {
+        const int k = 1 + tid + i * NT;
+        if (k <= L / 2) {
+            c2<T> xk, xlk;
+            untangle(s[k], conj(s[L - k]), uw[i], xk, xlk);
+            out[k] = mk<T>(xk.x * inv, xk.y * inv);
+            if (k != L - k) out[L - k] = mk<T>(xlk.x * inv, xlk.y * inv);
         }
     }
 }
@@ -441,21 +484,30 @@ template <typename T> struct MixSrc {
 };
 
 template <typename T, int LOG2L>
-__global__ __launch_bounds__(fft_threads(LOG2L)) void
+__global__ __launch_bounds__(fft_threads<T>(LOG2L)) void
 ring_fill_kernel(const FillJob<T> *__restrict__ jobs, const MixSrc<T> *__restrict__ src,
                  const c2<T> *__restrict__ tw, int N, unsigned int t) {
-    constexpr int L = 1 << LOG2L, NT = fft_threads(LOG2L);
+    constexpr int L = 1 << LOG2L, NT = fft_threads<T>(LOG2L);
+    constexpr int QP = UT<T, LOG2L>::QP, QU = UT<T, LOG2L>::QU;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    c2<T> *s = reinterpret_cast<c2<T> *>(smem);
+    LdsArr<T> s{reinterpret_cast<c2<T> *>(smem)};
     const int tid = threadIdx.x;
     const FillJob<T> job = jobs[blockIdx.x];
     c2<T> *dst = job.ring + (size_t)((t + (unsigned int)job.delay) % (unsigned int)N) * L;
     const MixSrc<T> *in = src + job.in_off;
     const MixSrc<T> *up = src + job.up_off;
+    TwRegs<T, LOG2L, NT> twr;
+    c2<T> uw[QU];
+#pragma unroll
+    for (int i = 0; i < QU; i++) { const int k = 1 + tid + i * NT; uw[i] = tw[k <= L / 2 ? k : 0]; }
 
     if (job.n_up > 0) {
+        twr.prefetch(tw);
         // M = sum_g fscale_g Y_g (mixnscale OUTPUT order), straight into the C2R pre-pass
-        for (int k = tid; k <= L / 2; k += NT) {
+#pragma unroll
+        for (int i = -1; i < QU; i++) {
+            const int k = i < 0 ? 0 : 1 + tid + i * NT;
+            if ((i < 0 && tid != 0) || k > L / 2) continue;
             c2<T> a = mk<T>(up[0].spec[k].x * up[0].scale, up[0].spec[k].y * up[0].scale);
             c2<T> b = mk<T>((T)0, (T)0);
             if (k != 0) b = mk<T>(up[0].spec[L - k].x * up[0].scale, up[0].spec[L - k].y * up[0].scale);
@@ -470,45 +522,46 @@ ring_fill_kernel(const FillJob<T> *__restrict__ jobs, const MixSrc<T> *__restric
             if (k == 0) {
                 s[0] = mk<T>(a.x + a.y, a.x - a.y);
             } else {
-                b = conj(b);
-                const c2<T> e = a + b, d = a - b;
-                const c2<T> o = cmul(d, conj(tw[k]));
-                s[k] = mk<T>(e.x - o.y, e.y + o.x);
-                if (k != L - k) s[L - k] = mk<T>(e.x + o.y, -e.y + o.x);
+                c2<T> zk, zlk;
+                tangle(a, conj(b), uw[i < 0 ? 0 : i], zk, zlk);
+                s[k] = zk;
+                if (k != L - k) s[L - k] = zlk;
             }
         }
         __syncthreads();
-        lds_fft<T, LOG2L, NT, true>(s, tw);
+        lds_fft<T, LOG2L, NT, true>(s, twr);
         // slide: z'[n] = prev pairs (n < L/2), z'[L/2 + n] = new valid pairs; prev <- new
-        constexpr int B = (L / 2 + NT - 1) / NT;
-        c2<T> v[B];
+        c2<T> v[QP];
+        c2<T> *ep = reinterpret_cast<c2<T> *>(job.evalprev);
 #pragma unroll
-        for (int b = 0; b < B; b++) {
+        for (int b = 0; b < QP; b++) {
             const int n = tid + b * NT;
             if (n < L / 2) v[b] = s[n];
         }
         __syncthreads();
 #pragma unroll
-        for (int b = 0; b < B; b++) {
+        for (int b = 0; b < QP; b++) {
             const int n = tid + b * NT;
             if (n < L / 2) {
                 s[L / 2 + n] = v[b];
-                s[n] = mk<T>(job.evalprev[2 * n], job.evalprev[2 * n + 1]);
-                job.evalprev[2 * n] = v[b].x;
-                job.evalprev[2 * n + 1] = v[b].y;
+                s[n] = ep[n];
+                ep[n] = v[b];
             }
         }
         __syncthreads();
-        lds_fft<T, LOG2L, NT, false>(s, tw);
+        lds_fft<T, LOG2L, NT, false>(s, twr);
     }
 
-    for (int k = tid; k <= L / 2; k += NT) {
+#pragma unroll
+    for (int i = -1; i < QU; i++) {
+        const int k = i < 0 ? 0 : 1 + tid + i * NT;
+        if ((i < 0 && tid != 0) || k > L / 2) continue;
         const int k2 = (k == 0 || k == L - k) ? -1 : L - k;
         c2<T> a = mk<T>((T)0, (T)0), b = mk<T>((T)0, (T)0);
         bool first = true;
-        for (int i = 0; i < job.n_in; i++) {
-            const c2<T> *sp = in[i].spec + (size_t)(t % (unsigned int)in[i].R) * L;
-            const T sc = in[i].scale;
+        for (int q = 0; q < job.n_in; q++) {
+            const c2<T> *sp = in[q].spec + (size_t)(t % (unsigned int)in[q].R) * L;
+            const T sc = in[q].scale;
             const c2<T> v = sp[k];
             if (first) a = mk<T>(v.x * sc, v.y * sc); else a = mk<T>(a.x + v.x * sc, a.y + v.y * sc);
             if (k2 >= 0) {
@@ -519,16 +572,8 @@ ring_fill_kernel(const FillJob<T> *__restrict__ jobs, const MixSrc<T> *__restric
         }
         if (job.n_up > 0) {
             c2<T> ek, ek2 = mk<T>((T)0, (T)0);
-            if (k == 0) {
-                ek = mk<T>(s[0].x + s[0].y, s[0].x - s[0].y);
-            } else {
-                const c2<T> za = s[k], zb = conj(s[L - k]);
-                const c2<T> e = mk<T>((T)0.5 * (za.x + zb.x), (T)0.5 * (za.y + zb.y));
-                const c2<T> d = mk<T>((T)0.5 * (za.x - zb.x), (T)0.5 * (za.y - zb.y));
-                const c2<T> wo = cmul(mk<T>(d.y, -d.x), tw[k]);
-                ek = e + wo;
-                ek2 = conj(e - wo);
-            }
+            if (k == 0) ek = mk<T>(s[0].x + s[0].y, s[0].x - s[0].y);
+            else untangle(s[k], conj(s[L - k]), uw[i < 0 ? 0 : i], ek, ek2);
             if (first) { a = ek; b = ek2; } else { a = a + ek; b = b + ek2; }
         }
         dst[k] = a;
@@ -602,48 +647,53 @@ mac_filter_kernel(const FilterJob<T> *__restrict__ jobs, int L, unsigned int t, 
 template <typename T> struct FadeJob { c2<T> *Ynew; const c2<T> *Yold; };
 
 template <typename T, int LOG2L>
-__device__ __forceinline__ void load_c2r(c2<T> *s, const c2<T> *__restrict__ z,
-                                         const c2<T> *__restrict__ tw) {
-    constexpr int L = 1 << LOG2L, NT = fft_threads(LOG2L);
-    for (int k = threadIdx.x; k <= L / 2; k += NT) {
-        const c2<T> a = z[k];
-        if (k == 0) {
-            s[0] = mk<T>(a.x + a.y, a.x - a.y);
-        } else {
-            const c2<T> b = conj(z[L - k]);
-            const c2<T> e = a + b, d = a - b;
-            const c2<T> o = cmul(d, conj(tw[k]));
-            s[k] = mk<T>(e.x - o.y, e.y + o.x);
-            if (k != L - k) s[L - k] = mk<T>(e.x + o.y, -e.y + o.x);
+__device__ __forceinline__ void load_c2r(LdsArr<T> s, const c2<T> *__restrict__ z,
+                                         const c2<T> *uw /* [QU] untangle twiddles */) {
+    constexpr int L = 1 << LOG2L, NT = fft_threads<T>(LOG2L), QU = UT<T, LOG2L>::QU;
+    const int tid = threadIdx.x;
+    if (tid == 0) { const c2<T> a = z[0]; s[0] = mk<T>(a.x + a.y, a.x - a.y); }
+#pragma unroll
+    for (int i = 0; i < QU; i++) {
+        const int k = 1 + tid + i * NT;
+        if (k <= L / 2) {
+            c2<T> zk, zlk;
+            tangle(z[k], conj(z[L - k]), uw[i], zk, zlk);
+            s[k] = zk;
+            if (k != L - k) s[L - k] = zlk;
         }
     }
 }
 
 template <typename T, int LOG2L>
-__global__ __launch_bounds__(fft_threads(LOG2L)) void
+__global__ __launch_bounds__(fft_threads<T>(LOG2L)) void
 crossfade_kernel(const FadeJob<T> *__restrict__ jobs, const c2<T> *__restrict__ tw) {
-    constexpr int L = 1 << LOG2L, NT = fft_threads(LOG2L);
+    constexpr int L = 1 << LOG2L, NT = fft_threads<T>(LOG2L);
+    constexpr int QP = UT<T, LOG2L>::QP, QU = UT<T, LOG2L>::QU;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    c2<T> *s = reinterpret_cast<c2<T> *>(smem);
+    LdsArr<T> s{reinterpret_cast<c2<T> *>(smem)};
     const int tid = threadIdx.x;
     const FadeJob<T> job = jobs[blockIdx.x];
-    constexpr int B = (L / 2 + NT - 1) / NT;
-    c2<T> oldv[B];
-
-    load_c2r<T, LOG2L>(s, job.Yold, tw);
-    __syncthreads();
-    lds_fft<T, LOG2L, NT, true>(s, tw);
+    TwRegs<T, LOG2L, NT> twr;
+    twr.prefetch(tw);
+    c2<T> uw[QU];
 #pragma unroll
-    for (int b = 0; b < B; b++) {
+    for (int i = 0; i < QU; i++) { const int k = 1 + tid + i * NT; uw[i] = tw[k <= L / 2 ? k : 0]; }
+    c2<T> oldv[QP];
+
+    load_c2r<T, LOG2L>(s, job.Yold, uw);
+    __syncthreads();
+    lds_fft<T, LOG2L, NT, true>(s, twr);
+#pragma unroll
+    for (int b = 0; b < QP; b++) {
         const int n = tid + b * NT;
         if (n < L / 2) oldv[b] = s[n];
     }
     __syncthreads();
-    load_c2r<T, LOG2L>(s, job.Ynew, tw);
+    load_c2r<T, LOG2L>(s, job.Ynew, uw);
     __syncthreads();
-    lds_fft<T, LOG2L, NT, true>(s, tw);
+    lds_fft<T, LOG2L, NT, true>(s, twr);
 #pragma unroll
-    for (int b = 0; b < B; b++) {
+    for (int b = 0; b < QP; b++) {
         const int n = tid + b * NT;
         if (n < L / 2) {
             c2<T> nv = s[n];
@@ -662,19 +712,17 @@ crossfade_kernel(const FadeJob<T> *__restrict__ jobs, const c2<T> *__restrict__ 
         }
     }
     __syncthreads();
-    lds_fft<T, LOG2L, NT, false>(s, tw);
+    lds_fft<T, LOG2L, NT, false>(s, twr);
     const T inv = (T)1.0 / (T)(2 * L);
-    for (int k = tid; k <= L / 2; k += NT) {
-        if (k == 0) {
-            job.Ynew[0] = mk<T>((s[0].x + s[0].y) * inv, (s[0].x - s[0].y) * inv);
-        } else {
-            const c2<T> a = s[k], b = conj(s[L - k]);
-            const c2<T> e = mk<T>((T)0.5 * (a.x + b.x), (T)0.5 * (a.y + b.y));
-            const c2<T> d = mk<T>((T)0.5 * (a.x - b.x), (T)0.5 * (a.y - b.y));
-            const c2<T> wo = cmul(mk<T>(d.y, -d.x), tw[k]);
-            const c2<T> x = e + wo, y = conj(e - wo);
-            job.Ynew[k] = mk<T>(x.x * inv, x.y * inv);
-            if (k != L - k) job.Ynew[L - k] = mk<T>(y.x * inv, y.y * inv);
+    if (tid == 0) job.Ynew[0] = mk<T>((s[0].x + s[0].y) * inv, (s[0].x - s[0].y) * inv);
+#pragma unroll
+    for (int i = 0; i < QU; i++) {
+        const int k = 1 + tid + i * NT;
+        if (k <= L / 2) {
+            c2<T> xk, xlk;
+            untangle(s[k], conj(s[L - k]), uw[i], xk, xlk);
+            job.Ynew[k] = mk<T>(xk.x * inv, xk.y * inv);
+            if (k != L - k) job.Ynew[L - k] = mk<T>(xlk.x * inv, xlk.y * inv);
         }
     }
 }
@@ -715,15 +763,16 @@ real2int_no_dither(double v, double rmin, double rmax, int32_t imin, int32_t ima
 // `timeout` (may be NULL): if given, the samples are ALSO stored there as T [count][L]
 // (used by the dither pass and by debug taps).
 template <typename T, int LOG2L>
-__global__ __launch_bounds__(fft_threads(LOG2L)) void
+__global__ __launch_bounds__(fft_threads<T>(LOG2L)) void
 ifft_out_kernel(const c2<T> *__restrict__ Zp, size_t chunk_stride, int n_chunks,
                 int first_channel, const DevFormat *__restrict__ fmt,
                 DevOverflow *__restrict__ over, const unsigned char *__restrict__ skip_quant,
                 uint8_t *__restrict__ raw, T *__restrict__ timeout,
                 const c2<T> *__restrict__ tw, double safety_limit, int *__restrict__ status) {
-    constexpr int L = 1 << LOG2L, NT = fft_threads(LOG2L);
+    constexpr int L = 1 << LOG2L, NT = fft_threads<T>(LOG2L);
+    constexpr int QU = UT<T, LOG2L>::QU;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    c2<T> *s = reinterpret_cast<c2<T> *>(smem);
+    LdsArr<T> s{reinterpret_cast<c2<T> *>(smem)};
     __shared__ unsigned int red_n[16];
     __shared__ int32_t red_i[16];
     __shared__ double red_l[16];
@@ -732,23 +781,41 @@ ifft_out_kernel(const c2<T> *__restrict__ Zp, size_t chunk_stride, int n_chunks,
     const int ch = first_channel + zi;         // output channel
     const c2<T> *z = Zp + (size_t)zi * L;
 
-    for (int k = tid; k <= L / 2; k += NT) {
-        c2<T> a = z[k];
-        for (int c = 1; c < n_chunks; c++) a = a + z[(size_t)c * chunk_stride + k];
-        if (k == 0) {
-            s[0] = mk<T>(a.x + a.y, a.x - a.y);
-        } else {
-            c2<T> b = z[L - k];
-            for (int c = 1; c < n_chunks; c++) b = b + z[(size_t)c * chunk_stride + L - k];
-            b = conj(b);
-            const c2<T> e = a + b, d = a - b;
-            const c2<T> o = cmul(d, conj(tw[k]));               // 2 O[k]
-            s[k] = mk<T>(e.x - o.y, e.y + o.x);                 // 2E + i 2O
-            if (k != L - k) s[L - k] = mk<T>(e.x + o.y, -e.y + o.x);   // conj(2E) + i conj(2O)
+    TwRegs<T, LOG2L, NT> twr;
+    twr.prefetch(tw);
+    c2<T> uw[QU], za[QU], zb[QU];
+    c2<T> z0 = mk<T>((T)0, (T)0);
+#pragma unroll
+    for (int i = 0; i < QU; i++) { const int k = 1 + tid + i * NT; uw[i] = tw[k <= L / 2 ? k : 0]; }
+    // chunk partials: all loads of one chunk are in flight together, chunks add up in order
+    for (int c = 0; c < n_chunks; c++) {
+        const c2<T> *zc = z + (size_t)c * chunk_stride;
+        c2<T> ta[QU], tb[QU];
+#pragma unroll
+        for (int i = 0; i < QU; i++) {
+            const int k = 1 + tid + i * NT;
+            if (k <= L / 2) { ta[i] = zc[k]; tb[i] = zc[L - k]; }
+        }
+        if (tid == 0) { const c2<T> t0 = zc[0]; z0 = c == 0 ? t0 : z0 + t0; }
+#pragma unroll
+        for (int i = 0; i < QU; i++) {
+            za[i] = c == 0 ? ta[i] : za[i] + ta[i];
+            zb[i] = c == 0 ? tb[i] : zb[i] + tb[i];
+        }
+    }
+    if (tid == 0) s[0] = mk<T>(z0.x + z0.y, z0.x - z0.y);
+#pragma unroll
+    for (int i = 0; i < QU; i++) {
+        const int k = 1 + tid + i * NT;
+        if (k <= L / 2) {
+            c2<T> zk, zlk;
+            tangle(za[i], conj(zb[i]), uw[i], zk, zlk);
+            s[k] = zk;
+            if (k != L - k) s[L - k] = zlk;
         }
     }
     __syncthreads();
-    lds_fft<T, LOG2L, NT, true>(s, tw);
+    lds_fft<T, LOG2L, NT, true>(s, twr);
 
     const DevFormat f = fmt[ch];
     DevOverflow of = over[ch];

@@ -143,10 +143,13 @@ int bfhip_engine_set_fscale(bfhip_engine *e, int filter, int index, double scale
 int bfhip_engine_block(bfhip_engine *e, const void *rawin, void *rawout,
                        bfhip_overflow overflow[]);
 
-/* Device-resident raw buffers, asynchronous on the engine's stream; complete after
-   bfhip_engine_sync().  (BFHIP_OVERLAP=1 in the environment queues the three kernels of a block
-   on three engine-owned streams so that the FFTs of neighbouring blocks run beside the MAC;
-   measured slower than the plain sequence on MI355X, kept as an experiment -- DESIGN.md.) */
+/* Device-resident raw buffers, asynchronous; rawin_dev must stay valid and rawout_dev is
+   complete only after bfhip_engine_sync().  For small crossbars (coefficient stream under
+   ~100 us per block) the three kernels of a block are queued on three engine-owned streams so
+   that the input FFT of the next block and the inverse FFT of the previous one run beside the
+   MAC, the way the reference overlaps its input, filter and output processes; for large ones
+   (the headline config) the plain sequence on one stream is faster.  BFHIP_OVERLAP=0/1 in the
+   environment forces either. */
 int bfhip_engine_block_dev(bfhip_engine *e, const void *rawin_dev, void *rawout_dev);
 /* wait for the stream; returns accumulated status bits (and clears them) or an error */
 int bfhip_engine_sync(bfhip_engine *e);
