@@ -101,6 +101,7 @@ def lib():
     L.bfhip_engine_inputs_dev.argtypes = [vp, vp]
     L.bfhip_engine_mac_dev.argtypes = [vp, vp]
     L.bfhip_engine_outputs_dev.argtypes = [vp, vp, ci, ci, vp]
+    L.bfhip_engine_outputs_inputs_dev.argtypes = [vp, vp, ci, ci, vp, vp]
     L.bfhip_engine_advance.argtypes = [vp]
     L.bfhip_engine_set_stream.argtypes = [vp, vp]
     L.bfhip_engine_get_overflow.argtypes = [vp, ci, C.POINTER(Overflow)]
@@ -258,6 +259,10 @@ class Engine:
 
     def outputs_dev(self, z_dev, first, count, rawout_dev):
         _check(lib().bfhip_engine_outputs_dev(self.h, _ptr(z_dev), first, count, _ptr(rawout_dev)))
+
+    def outputs_inputs_dev(self, z_dev, first, count, rawout_dev, rawin_dev):
+        _check(lib().bfhip_engine_outputs_inputs_dev(self.h, _ptr(z_dev), first, count,
+                                                     _ptr(rawout_dev), _ptr(rawin_dev)))
 
     def advance(self):
         _check(lib().bfhip_engine_advance(self.h))

@@ -246,6 +246,22 @@ void launch_ifft_out(bfhip_engine *e, const void *Zp, size_t chunk_stride, int n
     }
 }
 
+template <typename T, int LOG2L>
+void launch_io(bfhip_engine *e, const void *z, int first, int count, uint8_t *rawout,
+               const uint8_t *rawin, int slot, hipError_t *err) {
+    constexpr int NT = fft_threads<T>(LOG2L);
+    const size_t lds = lds_fft_bytes(LOG2L, sizeof(c2<T>));
+    auto k = io_kernel<T, LOG2L>;
+    *err = allow_lds(k, lds);
+    if (*err != hipSuccess) return;
+    hipLaunchKernelGGL(k, dim3(count + e->n_ch[0]), dim3(NT), lds, e->ls, count,
+                       (const c2<T> *)z, first, e->d_fmt[1], e->d_over, (const unsigned char *)e->d_skip_quant,
+                       rawout, e->d_timeout ? (T *)e->d_timeout + (size_t)first * e->L : (T *)nullptr,
+                       e->safety_limit, e->d_status,
+                       rawin, e->d_fmt[0], (T *)e->d_prev, (c2<T> *)e->d_ring, e->R, slot, (const c2<T> *)e->d_tw);
+    *err = hipGetLastError();
+}
+
 template <typename T>
 void launch_mac(bfhip_engine *e, void *Zp, hipError_t *err) {
     const int n_tc = e->n_tiles * e->n_chunks;
@@ -1210,6 +1226,24 @@ int bfhip_engine_outputs_dev(bfhip_engine *e, const void *z_dev, int first, int 
     if (r != BFHIP_OK) return r;
     if (first < 0 || count < 0 || first + count > e->n_ch[1]) return fail(BFHIP_EINVAL, "outputs: channel range");
     return do_outputs(e, z_dev, 0, 1, first, count, rawout_dev);
+}
+
+int bfhip_engine_outputs_inputs_dev(bfhip_engine *e, const void *z_dev, int first, int count,
+                                    void *rawout_dev, const void *rawin_dev) {
+    int r = ensure_ready(e);
+    if (r != BFHIP_OK) return r;
+    if (first < 0 || count < 0 || first + count > e->n_ch[1]) return fail(BFHIP_EINVAL, "outputs: channel range");
+    if (!e->dither_channels.empty() || count == 0) {
+        // the dither pass follows the inverse transforms: keep the two launches apart
+        if ((r = bfhip_engine_outputs_dev(e, z_dev, first, count, rawout_dev)) != BFHIP_OK) return r;
+        return bfhip_engine_inputs_dev(e, rawin_dev);
+    }
+    e->ls = e->stream;
+    hipError_t err = hipSuccess;
+    const int slot = (int)(e->blockcounter % (unsigned int)e->R);
+    DISPATCH(launch_io, e, z_dev, first, count, (uint8_t *)rawout_dev, (const uint8_t *)rawin_dev, slot, &err);
+    if (err != hipSuccess) return fail(BFHIP_EHIP, "io launch: %s", hipGetErrorString(err));
+    return BFHIP_OK;
 }
 
 int bfhip_engine_advance(bfhip_engine *e) {

@@ -157,16 +157,15 @@ __device__ __forceinline__ void tangle(c2<T> a, c2<T> bconj, c2<T> w, c2<T> &zk,
 // packed spectrum into ring slot `slot` of that channel.  All global loads (twiddles,
 // previous block, raw samples) are issued before anything waits on them.
 template <typename T, int LOG2L>
-__global__ __launch_bounds__(fft_threads<T>(LOG2L)) void
-fft_in_kernel(const uint8_t *__restrict__ raw, const DevFormat *__restrict__ fmt,
-              T *__restrict__ prev,            // [n_in][L] last block's samples
-              c2<T> *__restrict__ ring,        // [n_in][R][L]
-              const c2<T> *__restrict__ tw, int R, int slot) {
+__device__ __forceinline__ void
+fft_in_body(int ch, unsigned char *smem, const uint8_t *__restrict__ raw, const DevFormat *__restrict__ fmt,
+            T *__restrict__ prev,            // [n_in][L] last block's samples
+            c2<T> *__restrict__ ring,        // [n_in][R][L]
+            const c2<T> *__restrict__ tw, int R, int slot) {
     constexpr int L = 1 << LOG2L, NT = fft_threads<T>(LOG2L);
     constexpr int QP = UT<T, LOG2L>::QP, QU = UT<T, LOG2L>::QU;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     LdsArr<T> s{reinterpret_cast<c2<T> *>(smem)};
-    const int ch = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const DevFormat f = fmt[ch];
     c2<T> *pv = reinterpret_cast<c2<T> *>(prev + (size_t)ch * L);
     const uint8_t *base = raw + f.byte_offset;
@@ -212,6 +211,14 @@ fft_in_kernel(const uint8_t *__restrict__ raw, const DevFormat *__restrict__ fmt
             if (k != L - k) out[L - k] = xlk;
         }
     }
+}
+
+template <typename T, int LOG2L>
+__global__ __launch_bounds__(fft_threads<T>(LOG2L)) void
+fft_in_kernel(const uint8_t *__restrict__ raw, const DevFormat *__restrict__ fmt, T *__restrict__ prev,
+              c2<T> *__restrict__ ring, const c2<T> *__restrict__ tw, int R, int slot) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    fft_in_body<T, LOG2L>(blockIdx.x, smem, raw, fmt, prev, ring, tw, R, slot);
 }
 
 // ------------------------------------------------------------------ K7: taps -> coefficient partition
@@ -763,21 +770,20 @@ real2int_no_dither(double v, double rmin, double rmax, int32_t imin, int32_t ima
 // `timeout` (may be NULL): if given, the samples are ALSO stored there as T [count][L]
 // (used by the dither pass and by debug taps).
 template <typename T, int LOG2L>
-__global__ __launch_bounds__(fft_threads<T>(LOG2L)) void
-ifft_out_kernel(const c2<T> *__restrict__ Zp, size_t chunk_stride, int n_chunks,
-                int first_channel, const DevFormat *__restrict__ fmt,
-                DevOverflow *__restrict__ over, const unsigned char *__restrict__ skip_quant,
-                uint8_t *__restrict__ raw, T *__restrict__ timeout,
-                const c2<T> *__restrict__ tw, double safety_limit, int *__restrict__ status) {
+__device__ __forceinline__ void
+ifft_out_body(int zi /* index into Zp's channel axis */, unsigned char *smem,
+              const c2<T> *__restrict__ Zp, size_t chunk_stride, int n_chunks,
+              int first_channel, const DevFormat *__restrict__ fmt,
+              DevOverflow *__restrict__ over, const unsigned char *__restrict__ skip_quant,
+              uint8_t *__restrict__ raw, T *__restrict__ timeout,
+              const c2<T> *__restrict__ tw, double safety_limit, int *__restrict__ status) {
     constexpr int L = 1 << LOG2L, NT = fft_threads<T>(LOG2L);
     constexpr int QU = UT<T, LOG2L>::QU;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     LdsArr<T> s{reinterpret_cast<c2<T> *>(smem)};
     __shared__ unsigned int red_n[16];
     __shared__ int32_t red_i[16];
     __shared__ double red_l[16];
     const int tid = threadIdx.x;
-    const int zi = blockIdx.x;                 // index into Zp's channel axis
     const int ch = first_channel + zi;         // output channel
     const c2<T> *z = Zp + (size_t)zi * L;
 
@@ -901,6 +907,38 @@ ifft_out_kernel(const c2<T> *__restrict__ Zp, size_t chunk_stride, int n_chunks,
         over[ch].largest = largest;
         if (st) atomicOr(status, st);
     }
+}
+
+template <typename T, int LOG2L>
+__global__ __launch_bounds__(fft_threads<T>(LOG2L)) void
+ifft_out_kernel(const c2<T> *__restrict__ Zp, size_t chunk_stride, int n_chunks, int first_channel,
+                const DevFormat *__restrict__ fmt, DevOverflow *__restrict__ over,
+                const unsigned char *__restrict__ skip_quant, uint8_t *__restrict__ raw,
+                T *__restrict__ timeout, const c2<T> *__restrict__ tw, double safety_limit,
+                int *__restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ifft_out_body<T, LOG2L>(blockIdx.x, smem, Zp, chunk_stride, n_chunks, first_channel, fmt, over,
+                            skip_quant, raw, timeout, tw, safety_limit, status);
+}
+
+// K3 of one block and K1 of a later block in ONE launch: the first n_k3 workgroups do the
+// inverse transforms, the rest the forward ones.  For a host that pipelines blocks (multi-GPU:
+// the mix-down of block t is in flight while block t+1 is computed) the two are independent
+// and each is only a handful of workgroups, so running them side by side hides one launch.
+template <typename T, int LOG2L>
+__global__ __launch_bounds__(fft_threads<T>(LOG2L)) void
+io_kernel(int n_k3,
+          const c2<T> *__restrict__ Zp, int first_channel, const DevFormat *__restrict__ fmt_out,
+          DevOverflow *__restrict__ over, const unsigned char *__restrict__ skip_quant,
+          uint8_t *__restrict__ rawout, T *__restrict__ timeout, double safety_limit, int *__restrict__ status,
+          const uint8_t *__restrict__ rawin, const DevFormat *__restrict__ fmt_in, T *__restrict__ prev,
+          c2<T> *__restrict__ ring, int R, int slot, const c2<T> *__restrict__ tw) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if ((int)blockIdx.x < n_k3)
+        ifft_out_body<T, LOG2L>(blockIdx.x, smem, Zp, 0, 1, first_channel, fmt_out, over, skip_quant,
+                                rawout, timeout, tw, safety_limit, status);
+    else
+        fft_in_body<T, LOG2L>((int)blockIdx.x - n_k3, smem, rawin, fmt_in, prev, ring, tw, R, slot);
 }
 
 // ------------------------------------------------------------------ K3d: HP-TPDF dithered requantiser

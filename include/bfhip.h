@@ -165,6 +165,11 @@ int bfhip_engine_inputs_dev(bfhip_engine *e, const void *rawin_dev);
 int bfhip_engine_mac_dev(bfhip_engine *e, void *z_dev);
 int bfhip_engine_outputs_dev(bfhip_engine *e, const void *z_dev, int first, int count,
                              void *rawout_dev);
+/* outputs of an EARLIER block (spectra in z_dev) and inputs of the CURRENT block in one launch:
+   for a host that keeps several blocks in flight (the mix-down of block t travels while block
+   t+1 is computed) the two are independent, and one launch instead of two shortens the step */
+int bfhip_engine_outputs_inputs_dev(bfhip_engine *e, const void *z_dev, int first, int count,
+                                    void *rawout_dev, const void *rawin_dev);
 /* advance blockcounter / curbuf (bfrun.c:2031-2034); block/block_dev do it themselves */
 int bfhip_engine_advance(bfhip_engine *e);
 

@@ -96,3 +96,59 @@ def test_two_ranks_on_one_gpu_match_the_unsharded_engine(hip):
         assert st == 0
         err = cases.rel_rms(got, want[:, :, fo:fo + co])
         assert err <= 1e-6, (rank, err)        # same kernels, only the summation order differs
+
+
+def test_phase_api_and_fused_io_launch_equal_the_block_call(hip):
+    """inputs / mac / outputs as separate phases, and the fused `outputs of block k-2 + inputs
+    of block k` launch bench.py uses at N > 1, give bit-identical samples to block()"""
+    import torch
+    import cases
+    Lq, Nq, Iq, Oq = 2048, 4, 3, 5
+    dev = torch.device("cuda", 0)
+    ref_e, _ = cases.crossbar(hip.Engine, Lq, Nq, 4, Iq, Oq, FMT, "FLOAT_LE")
+    pipe_e, _ = cases.crossbar(hip.Engine, Lq, Nq, 4, Iq, Oq, FMT, "FLOAT_LE")
+    pipe_e.set_stream(torch.cuda.current_stream().cuda_stream)
+    blocks = cases.raw_blocks(77, Nq + 5, Lq, Iq, FMT)
+    want = []
+    for blk in blocks:
+        st, raw = ref_e.block(blk)
+        assert st == 0
+        want.append(np.frombuffer(raw.tobytes(), np.float32).reshape(Lq, Oq).copy())
+    srcs = [torch.from_numpy(b).to(dev) for b in blocks]
+    z = [torch.zeros(Oq, Lq, 2, dtype=torch.float32, device=dev) for _ in range(3)]
+    out = torch.zeros(Lq, Oq, dtype=torch.float32, device=dev)
+    got = {}
+    for k, src in enumerate(srcs):
+        if k >= 2:
+            pipe_e.outputs_inputs_dev(z[(k - 2) % 3], 0, Oq, out, src)
+            torch.cuda.synchronize()
+            got[k - 2] = out.cpu().numpy().copy()
+        else:
+            pipe_e.inputs_dev(src)
+        pipe_e.mac_dev(z[k % 3])
+        pipe_e.advance()
+    for k in (len(srcs) - 2, len(srcs) - 1):
+        pipe_e.outputs_dev(z[k % 3], 0, Oq, out)
+        torch.cuda.synchronize()
+        got[k] = out.cpu().numpy().copy()
+    assert pipe_e.sync() == 0
+    for k in range(len(srcs)):
+        assert np.array_equal(got[k], want[k]), k
+
+
+def test_bench_two_rank_pipeline_on_one_gpu():
+    """bench.py's N > 1 code path end to end (torch.distributed.run, sharding, the two-deep
+    block pipeline with the fused launch), two ranks sharing cuda:0 over gloo, small workload;
+    the JSON line must come out and report no status bits"""
+    import json
+    import subprocess
+    env = dict(os.environ, BFHIP_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "10",
+                        "--workload", "B"], capture_output=True, text=True, timeout=280, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 0
+    assert d["config"]["status_bits"] == 0 and d["scaling"] == "strong"
