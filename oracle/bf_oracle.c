@@ -348,6 +348,182 @@ bfo_cbuf2raw(bfo_ctx *c, const void *cbuf, void *outbuf, const bfo_format *bf,
                       L, of, safety_limit, NULL, NULL);
 }
 
+/* ================================================ integer delay (delay.c:78-340) */
+
+struct bfo_delay {
+    int F, ss;            /* fragment size in samples, bytes per sample */
+    int maxdelay, curdelay, cur, n_full, n_full_cap, n_rest;
+    uint8_t **full;       /* whole-fragment buffers */
+    uint8_t *rest;        /* rest buffer */
+    uint8_t *shrt[2];     /* the two "short" buffers used while delay <= fragment */
+};
+
+static uint8_t *
+zbytes(size_t n)
+{
+    return calloc(n ? n : 1, 1);
+}
+
+bfo_delay *
+bfo_delay_new(int fragment_size, int initdelay, int maxdelay, int sample_size)
+{
+    bfo_delay *d = calloc(1, sizeof(*d));
+    const size_t frag = (size_t)fragment_size * sample_size;
+    int delay, n;
+    d->F = fragment_size; d->ss = sample_size;
+    delay = maxdelay <= 0 ? initdelay : maxdelay;                 /* delay.c:357-360 */
+    if (maxdelay >= 0 && delay > maxdelay) delay = initdelay = maxdelay;
+    d->curdelay = initdelay;
+    d->maxdelay = maxdelay;
+    if (delay == 0) return d;
+    if (delay <= fragment_size) {                                 /* :365-374 */
+        d->n_rest = initdelay;
+        d->shrt[0] = zbytes((size_t)delay * sample_size);
+        d->shrt[1] = zbytes((size_t)delay * sample_size);
+        return d;
+    }
+    if (maxdelay > 0) { d->shrt[0] = zbytes(frag); d->shrt[1] = zbytes(frag); }
+    d->n_rest = initdelay % fragment_size;
+    d->n_full = initdelay / fragment_size + 1;
+    if (d->n_full == 1) d->n_full = 0;
+    d->n_full_cap = delay / fragment_size + 1;
+    d->full = calloc(d->n_full_cap, sizeof(uint8_t *));
+    for (n = 0; n < d->n_full_cap; n++) d->full[n] = zbytes(frag);
+    if (maxdelay > 0) d->rest = zbytes(frag);
+    else if (d->n_rest != 0) d->rest = zbytes((size_t)d->n_rest * sample_size);
+    return d;
+}
+
+void
+bfo_delay_free(bfo_delay *d)
+{
+    int n;
+    if (d == NULL) return;
+    for (n = 0; n < d->n_full_cap; n++) free(d->full[n]);
+    free(d->full); free(d->rest); free(d->shrt[0]); free(d->shrt[1]); free(d);
+}
+
+static void
+delay_retarget(bfo_delay *d, int newdelay)                        /* change_delay, :283-318 */
+{
+    int i;
+    if (newdelay == d->curdelay || newdelay > d->maxdelay) return;
+    if (newdelay <= d->F) {
+        d->n_rest = newdelay;
+        if (d->curdelay > d->F || d->curdelay < newdelay) {
+            memset(d->shrt[0], 0, (size_t)newdelay * d->ss);
+            memset(d->shrt[1], 0, (size_t)newdelay * d->ss);
+        }
+        d->n_full = 0; d->cur = 0; d->curdelay = newdelay;
+        return;
+    }
+    d->n_rest = newdelay % d->F;
+    d->n_full = newdelay / d->F + 1;
+    if (d->curdelay < newdelay) {
+        for (i = 0; i < d->n_full; i++) memset(d->full[i], 0, (size_t)d->F * d->ss);
+        if (d->n_rest != 0) memset(d->rest, 0, (size_t)d->n_rest * d->ss);
+    }
+    d->cur = 0; d->curdelay = newdelay;
+}
+
+void
+bfo_delay_update(bfo_delay *d, void *buf_, int delay)
+{
+    uint8_t *buf = buf_;
+    const size_t ss = d->ss, F = d->F, r = d->n_rest;
+    delay_retarget(d, delay);
+    if (d->n_full > 0) {                                          /* update_delay_buffer */
+        uint8_t *last = d->cur == d->n_full - 1 ? d->full[0] : d->full[d->cur + 1];
+        const size_t rr = d->n_rest;
+        memcpy(d->full[d->cur], buf, F * ss);
+        if (rr != 0) {
+            memcpy(buf, d->rest, rr * ss);
+            memcpy(d->rest, last + (F - rr) * ss, rr * ss);
+        }
+        memcpy(buf + rr * ss, last, (F - rr) * ss);
+        if (++d->cur == d->n_full) d->cur = 0;
+    } else if (d->n_rest > 0) {                                   /* update_delay_short_buffer */
+        const size_t rr = d->n_rest;
+        memcpy(d->shrt[d->cur], buf + (F - rr) * ss, rr * ss);
+        memmove(buf + rr * ss, buf, (F - rr) * ss);
+        d->cur = !d->cur;
+        memcpy(buf, d->shrt[d->cur], rr * ss);
+    }
+    (void)r;
+}
+
+/* ================================================ Kaiser window (firwindow.c) */
+
+static double
+bessel_i0(double x)
+{
+    double n = 1.0, a = 1.0, sum = 1.0;
+    const double h = x / 2.0;
+    do {
+        a *= h; a /= n;
+        sum += a * a;
+        n += 1.0;
+    } while (a != 0.0 && isfinite(sum));
+    return sum;
+}
+
+static double
+kaiser_at(double x, double beta, double inv)
+{
+    if (x < -1.0) x = -1.0;
+    if (x > 1.0) x = 1.0;
+    return bessel_i0(beta * sqrt(1.0 - x * x)) * inv;
+}
+
+static void
+wmul(void *t, int realsize, int n, double y)
+{
+    if (realsize == 4) ((float *)t)[n] *= y; else ((double *)t)[n] *= y;
+}
+
+void
+bfo_firwindow_kaiser(void *target, int len, double offset, double beta, int realsize)
+{
+    const int half = len >> 1;
+    const double inv = 1.0 / bessel_i0(beta);
+    int n, max;
+    double step;
+    if (offset != 0.0) {
+        max = half + (int)floor(offset);
+        offset -= floor(offset);
+        if (fabs(offset) < 1e-20) offset = 0.0;
+        step = 1.0 / ((double)max + offset);
+        if (offset == 0.0) max -= 1;
+        for (n = 0; n <= max; n++) {
+            const double y = kaiser_at(-1.0 + (double)n * step, beta, inv);
+            wmul(target, realsize, n, y);         /* applied twice in the reference (:105-110) */
+            wmul(target, realsize, n, y);
+        }
+        if (offset == 0.0) max += 1;
+        step = 1.0 / ((double)(len - max - 1) - offset);
+        for (; n < len; n++) {
+            const double y = kaiser_at(((double)(n - max) - offset) * step, beta, inv);
+            wmul(target, realsize, n, y);
+            wmul(target, realsize, n, y);
+        }
+    } else if (len & 1) {
+        step = 1.0 / (double)half;
+        for (n = 1; n <= half; n++) {
+            const double y = kaiser_at((double)n * step, beta, inv);
+            wmul(target, realsize, half + n, y);
+            wmul(target, realsize, half - n, y);
+        }
+    } else {
+        step = 1.0 / (double)half;
+        step *= (double)half / ((double)half - 0.5);
+        for (n = 1; n <= half; n++) {
+            const double y = kaiser_at(((double)n - 0.5) * step, beta, inv);
+            wmul(target, realsize, half + n - 1, y);
+            wmul(target, realsize, half - n, y);
+        }
+    }
+}
+
 /* ============================================================== block level */
 
 typedef struct {

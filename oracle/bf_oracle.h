@@ -95,6 +95,16 @@ int bfo_dither_randtab_ptr(const bfo_ctx *c, int channel);
 int bfo_cbuf2raw(bfo_ctx *c, const void *cbuf, void *outbuf, const bfo_format *bf,
                  int dither_channel, bfo_overflow *overflow, double safety_limit);
 
+/* ---- integer sample delay, delay.c:78-340 (contiguous buffers: the way filter_process()
+   uses it for N:1 mapped channels, bfrun.c:1517-1521,1948).  Pinned bit-exactly against the
+   reference's delay.c incl. run-time delay changes (tests/test_oracle_delay.py). */
+typedef struct bfo_delay bfo_delay;
+bfo_delay *bfo_delay_new(int fragment_size, int initdelay, int maxdelay, int sample_size);
+void bfo_delay_free(bfo_delay *d);
+void bfo_delay_update(bfo_delay *d, void *buf, int delay);   /* buf: fragment_size samples */
+/* firwindow_kaiser, firwindow.c:80-160 (incl. its double application for offset != 0) */
+void bfo_firwindow_kaiser(void *target, int len, double offset, double beta, int realsize);
+
 /* ---- block level: the contract of one filter_process() iteration --------------- */
 /* (bfrun.c:1420-2083).  1:1 virtual/physical channels, no sub-sample
    delay, no powersave (it changes no sample), events not modelled. */

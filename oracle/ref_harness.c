@@ -44,6 +44,8 @@
 #include "dither.h"
 #include "numunion.h"
 #include "asmprot.h"
+#include "delay.h"
+#include "firwindow.h"
 
 static int n_fft, n_fft2;
 
@@ -302,4 +304,24 @@ int
 ref_dither_randtab_ptr(int channel)
 {
     return bfconf->dither_state[channel]->randtab_ptr;
+}
+
+/* ---- integer sample delay (delay.c:78-340) and the Kaiser window (firwindow.c) ---------- */
+
+void *
+ref_delay_allocate(int fragment_size, int initdelay, int maxdelay, int sample_size)
+{
+    return delay_allocate_buffer(fragment_size, initdelay, maxdelay, sample_size);
+}
+
+void
+ref_delay_update(void *db, void *buf, int sample_size, int sample_spacing, int delay, void *target)
+{
+    delay_update((delaybuffer_t *)db, buf, sample_size, sample_spacing, delay, target);
+}
+
+void
+ref_firwindow_kaiser(void *target, int len, double offset, double beta, int realsize)
+{
+    firwindow_kaiser(target, len, offset, beta, realsize);
 }

@@ -138,6 +138,29 @@ def dither(R, rs, seed):
             "of": ofs, "randtab_ptr": ptrs, "rate": np.int32(rate)}
 
 
+
+def delay_and_window(R):
+    """integer delay sequences (tests/test_oracle_delay.py CASES) and Kaiser windows through the
+    reference's delay.c / firwindow.c"""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import test_oracle_delay as tod
+    out = {}
+    for idx, case in enumerate(tod.CASES):
+        F, ss, init, maxd, delays = case
+        data = tod._data(case, idx)
+        out["in%d" % idx] = data
+        out["out%d" % idx] = tod._ref_run(R, F, ss, init, maxd, delays, data)
+    R.ref_firwindow_kaiser.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int]
+    for rs in (4, 8):
+        dt = np.float32 if rs == 4 else np.float64
+        for k, (ln, off) in enumerate([(63, 0.0), (63, 0.37), (63, -0.25), (64, 0.0), (31, 0.99), (31, -0.01)]):
+            t = np.ones(ln, dt)
+            R.ref_firwindow_kaiser(p(t), ln, off, 9.0, rs)
+            out["kaiser%d_%d" % (rs, k)] = t
+    np.savez_compressed(os.path.join(HERE, "ref_delay.npz"), **out)
+
+
+
 def main():
     R = bo.ref()
     if R is None:
@@ -145,6 +168,8 @@ def main():
     for rs, tag in ((4, "f32"), (8, "f64")):
         np.savez_compressed(os.path.join(HERE, "ref_ops_%s.npz" % tag), **ops(R, rs, 100 + rs))
         np.savez_compressed(os.path.join(HERE, "ref_conv_%s.npz" % tag), **conversions(R, rs, 200 + rs))
+    if len(sys.argv) == 1:
+        delay_and_window(R)
     # dither state is process-global in the reference: one precision per process
     which = sys.argv[1] if len(sys.argv) > 1 else None
     if which in ("f32", "f64"):
