@@ -562,6 +562,13 @@ struct bfo_engine {
     void *static_eval, *xfade[2], *tmp_out;
     int curbuf;
     unsigned int blockcounter;
+    /* virtual -> physical channel mapping (bfconf->virt2phys, n_virtperphys); 1:1 by default.
+       fmt[], dither_ch[] are indexed by PHYSICAL channel, everything else by virtual */
+    int n_phys[2];
+    int *v2p[2], *n_vpp[2];
+    int *delay[2], *maxdelay[2], *muted[2];
+    bfo_delay **db[2];              /* input_db / output_db, bfrun.c:1059-1060 */
+    void *incopy, *mixbuf;
 };
 
 static void *
@@ -589,6 +596,18 @@ bfo_engine_new(int length, int n_blocks, int realsize, int n_in, int n_out)
             b->sample_spacing = 1; b->byte_offset = n * length * realsize;
         }
     }
+    for (io = 0; io < 2; io++) {
+        e->n_phys[io] = e->n_ch[io];
+        e->v2p[io] = malloc(e->n_ch[io] * sizeof(int));
+        e->n_vpp[io] = malloc(e->n_ch[io] * sizeof(int));
+        e->delay[io] = calloc(e->n_ch[io], sizeof(int));
+        e->maxdelay[io] = calloc(e->n_ch[io], sizeof(int));
+        e->muted[io] = calloc(e->n_ch[io], sizeof(int));
+        e->db[io] = calloc(e->n_ch[io], sizeof(bfo_delay *));
+        for (n = 0; n < e->n_ch[io]; n++) { e->v2p[io][n] = n; e->n_vpp[io][n] = 1; }
+    }
+    e->incopy = calloc((size_t)length, 8);
+    e->mixbuf = calloc((size_t)length, realsize);
     e->dither_ch = malloc(n_out * sizeof(int));
     e->overflow = calloc(n_out, sizeof(bfo_overflow));
     for (n = 0; n < n_out; n++) { e->dither_ch[n] = -1; e->overflow[n].max = 1.0; }
@@ -629,6 +648,12 @@ bfo_engine_free(bfo_engine *e)
     for (n = 0; n < e->n_ch[1]; n++) free(e->out_freq[n]);
     free(e->in_time[0]); free(e->in_time[1]); free(e->in_freq); free(e->out_freq);
     free(e->static_eval); free(e->xfade[0]); free(e->xfade[1]); free(e->tmp_out);
+    for (n = 0; n < 2; n++) {
+        for (i = 0; i < e->n_ch[n]; i++) bfo_delay_free(e->db[n][i]);
+        free(e->v2p[n]); free(e->n_vpp[n]); free(e->delay[n]); free(e->maxdelay[n]);
+        free(e->muted[n]); free(e->db[n]);
+    }
+    free(e->incopy); free(e->mixbuf);
     free(e->fmt[0]); free(e->fmt[1]); free(e->dither_ch); free(e->overflow);
     free(e->f); free(e->co);
     bfo_ctx_free(e->c);
@@ -638,12 +663,16 @@ bfo_engine_free(bfo_engine *e)
 void
 bfo_engine_set_format(bfo_engine *e, int io, int ch, const bfo_format *bf)
 {
-    e->fmt[io][ch] = *bf;
+    int v;
+    e->fmt[io][ch] = *bf;                       /* ch is a PHYSICAL channel */
     if (io == 1) {
-        /* bfrun.c:2270-2277 */
-        memset(&e->overflow[ch], 0, sizeof(bfo_overflow));
-        e->overflow[ch].max = bf->isfloat ? 1.0
-            : (double)((uint64_t)1 << ((bf->sbytes << 3) - 1)) - 1;
+        /* bfrun.c:2270-2277: every virtual channel of that physical one */
+        for (v = 0; v < e->n_ch[1]; v++) {
+            if (e->v2p[1][v] != ch) continue;
+            memset(&e->overflow[v], 0, sizeof(bfo_overflow));
+            e->overflow[v].max = bf->isfloat ? 1.0
+                : (double)((uint64_t)1 << ((bf->sbytes << 3) - 1)) - 1;
+        }
     }
 }
 
@@ -662,6 +691,29 @@ bfo_engine_enable_dither(bfo_engine *e, const int out_channels[], int n, int sam
     for (i = 0; i < n; i++) e->dither_ch[out_channels[i]] = i;
     return 1;
 }
+
+int
+bfo_engine_map_channels(bfo_engine *e, int io, int n_phys, const int virt2phys[])
+{
+    int v;
+    if (n_phys < 1 || n_phys > e->n_ch[io]) return 0;
+    for (v = 0; v < e->n_phys[io]; v++) e->n_vpp[io][v] = 0;
+    for (v = 0; v < n_phys; v++) e->n_vpp[io][v] = 0;
+    for (v = 0; v < e->n_ch[io]; v++) {
+        if (virt2phys[v] < 0 || virt2phys[v] >= n_phys) return 0;
+        /* the virtual channels of one physical channel are consecutive (bfrun.c:1981 counts
+           them as they come) */
+        if (v > 0 && virt2phys[v] < virt2phys[v - 1]) return 0;
+        e->v2p[io][v] = virt2phys[v];
+        e->n_vpp[io][virt2phys[v]]++;
+    }
+    e->n_phys[io] = n_phys;
+    return 1;
+}
+
+void bfo_engine_set_delay(bfo_engine *e, int io, int ch, int delay) { e->delay[io][ch] = delay; }
+void bfo_engine_set_maxdelay(bfo_engine *e, int io, int ch, int maxdelay) { e->maxdelay[io][ch] = maxdelay; }
+void bfo_engine_set_mute(bfo_engine *e, int io, int ch, int muted) { e->muted[io][ch] = muted; }
 
 int
 bfo_engine_add_coeff(bfo_engine *e, const void *taps, int n_taps, double scale, int n_blocks)
@@ -772,7 +824,27 @@ bfo_engine_block(bfo_engine *e, const void *rawin, void *rawout)
 
     /* bfrun.c:1494-1560: raw -> sliding window -> spectrum, per input channel */
     for (n = 0; n < e->n_ch[0]; n++) {
-        bfo_raw2cbuf(c, rawin, e->in_time[cur][n], e->in_time[!cur][n], &e->fmt[0][n]);
+        const int ph = e->v2p[0][n];
+        const bfo_format *bf = &e->fmt[0][ph];
+        if (e->n_vpp[0][ph] == 1) {
+            bfo_raw2cbuf(c, rawin, e->in_time[cur][n], e->in_time[!cur][n], bf);
+        } else {
+            /* :1509-1531: several virtual inputs share a physical one: private copy of the raw
+               samples, integer delay or mute applied here (dai.c does it for 1:1 channels) */
+            bfo_format cf = *bf;
+            cf.sample_spacing = 1; cf.byte_offset = 0;
+            if (!e->muted[0][n]) {
+                const uint8_t *src = (const uint8_t *)rawin + bf->byte_offset;
+                const size_t st = (size_t)bf->sample_spacing * bf->bytes;
+                for (i = 0; i < e->L; i++) memcpy((uint8_t *)e->incopy + (size_t)i * bf->bytes, src + i * st, bf->bytes);
+                if (e->db[0][n] == NULL)
+                    e->db[0][n] = bfo_delay_new(e->L, e->delay[0][n], e->maxdelay[0][n], bf->bytes);
+                bfo_delay_update(e->db[0][n], e->incopy, e->delay[0][n]);
+            } else {
+                memset(e->incopy, 0, (size_t)e->L * bf->bytes);
+            }
+            bfo_raw2cbuf(c, e->incopy, e->in_time[cur][n], e->in_time[!cur][n], &cf);
+        }
         bfo_time2freq(c, e->in_time[cur][n], e->in_freq[n]);
     }
 
@@ -794,7 +866,7 @@ bfo_engine_block(bfo_engine *e, const void *rawin, void *rawout)
         nmix = f->n_in_ch;
         for (i = 0; i < f->n_in_ch; i++) {
             mix_in[i] = e->in_freq[f->in_ch[i]];
-            scales[i] = f->scale_in[i] * e->fmt[0][f->in_ch[i]].scale;   /* :1641 */
+            scales[i] = f->scale_in[i] * e->fmt[0][e->v2p[0][f->in_ch[i]]].scale;   /* :1641, virtscales */
         }
         if (f->n_in_f > 0) {
             /* :1603-1649 filter inputs: mix upstream outputs, re-window in time domain */
@@ -847,31 +919,62 @@ bfo_engine_block(bfo_engine *e, const void *rawin, void *rawout)
         f->prevcoeff = coeff;
     }
 
-    /* :1847-1868 output mix, then :1877-1936 inverse FFT + quantise, per output */
-    for (n = 0; n < e->n_ch[1]; n++) {
-        void *src[e->n_filters > 0 ? e->n_filters : 1];
-        double scales[e->n_filters > 0 ? e->n_filters : 1];
-        int cnt = 0, j, r;
-        for (i = 0; i < e->n_filters; i++) {
-            for (j = 0; j < e->f[i].n_out_ch; j++) {
-                if (e->f[i].out_ch[j] == n) {
-                    src[cnt] = e->f[i].ocbuf;
-                    scales[cnt] = e->f[i].scale_out[j] / e->fmt[1][n].scale;   /* :1850 */
-                    cnt++;
-                    break;
+    /* :1847-1868 output mix, then :1877-2003 inverse FFT, (delay / mute / N:1 mix), quantise */
+    {
+        int filled = 0, seen = 0;
+        for (n = 0; n < e->n_ch[1]; n++) {
+            void *src[e->n_filters > 0 ? e->n_filters : 1];
+            double scales[e->n_filters > 0 ? e->n_filters : 1];
+            const int ph = e->v2p[1][n];
+            const bfo_format *bf = &e->fmt[1][ph];
+            int cnt = 0, j, r = 0;
+            for (i = 0; i < e->n_filters; i++) {
+                for (j = 0; j < e->f[i].n_out_ch; j++) {
+                    if (e->f[i].out_ch[j] == n) {
+                        src[cnt] = e->f[i].ocbuf;
+                        scales[cnt] = e->f[i].scale_out[j] / bf->scale;       /* :1850 */
+                        cnt++;
+                        break;
+                    }
                 }
             }
+            if (cnt == 0) {
+                memset(e->out_freq[n], 0, (size_t)2 * e->L * e->rs);
+            } else {
+                bfo_mixnscale(c, src, e->out_freq[n], scales, cnt, BFO_MIX_OUTPUT);
+            }
+            bfo_freq2time(c, e->out_freq[n], e->tmp_out);
+            if (e->n_vpp[1][ph] == 1) {
+                /* :1926-1936; the probe of sample 0 (:1903-1911) is subsumed by cbuf2raw's test */
+                r = bfo_cbuf2raw(e->c, e->tmp_out, rawout, bf, e->dither_ch[ph], &e->overflow[n],
+                                 e->safety_limit);
+            } else {
+                /* :1938-2003 */
+                if (e->db[1][n] == NULL)
+                    e->db[1][n] = bfo_delay_new(e->L, e->delay[1][n], e->maxdelay[1][n], e->rs);
+                bfo_delay_update(e->db[1][n], e->tmp_out, e->delay[1][n]);
+                if (!e->muted[1][n]) {
+                    if (!filled) {
+                        memcpy(e->mixbuf, e->tmp_out, (size_t)e->L * e->rs);
+                    } else if (e->rs == 4) {
+                        for (i = 0; i < e->L; i++) ((float *)e->mixbuf)[i] += ((float *)e->tmp_out)[i];
+                    } else {
+                        for (i = 0; i < e->L; i++) ((double *)e->mixbuf)[i] += ((double *)e->tmp_out)[i];
+                    }
+                    filled = 1;
+                }
+                if (++seen == e->n_vpp[1][ph]) {
+                    bfo_overflow of = e->overflow[n];
+                    if (!filled) memset(e->mixbuf, 0, (size_t)e->L * e->rs);
+                    r = bfo_cbuf2raw(e->c, e->mixbuf, rawout, bf, e->dither_ch[ph], &of, e->safety_limit);
+                    for (i = 0; i < e->n_ch[1]; i++) {
+                        if (e->v2p[1][i] == ph) e->overflow[i] = of;
+                    }
+                    seen = 0; filled = 0;
+                }
+            }
+            if (r != 0 && status == 0) status = r;
         }
-        if (cnt == 0) {
-            memset(e->out_freq[n], 0, (size_t)2 * e->L * e->rs);
-        } else {
-            bfo_mixnscale(c, src, e->out_freq[n], scales, cnt, BFO_MIX_OUTPUT);
-        }
-        bfo_freq2time(c, e->out_freq[n], e->tmp_out);
-        /* :1903-1911 probe of sample 0 is subsumed by the per-sample test below */
-        r = bfo_cbuf2raw(e->c, e->tmp_out, rawout, &e->fmt[1][n], e->dither_ch[n],
-                         &e->overflow[n], e->safety_limit);
-        if (r != 0 && status == 0) status = r;
     }
 
     e->curbuf = !cur;

@@ -116,6 +116,15 @@ void bfo_engine_set_safety_limit(bfo_engine *e, double limit);
 /* bfconf.c:3170-3230 decides which outputs dither; here the caller says which */
 int bfo_engine_enable_dither(bfo_engine *e, const int out_channels[], int n,
                              int sample_rate, int max_size);
+/* N:1 virtual -> physical channel mapping (`mapping:` in the config; bfconf->virt2phys).
+   Virtual channels of one physical channel must be consecutive.  After this call
+   set_format / enable_dither address PHYSICAL channels.  For channels that share a physical
+   one, integer delay and mute are applied inside the block (bfrun.c:1509-1531,1938-2003);
+   for 1:1 channels they are dai.c's business and ignored here.  Returns 1 / 0. */
+int bfo_engine_map_channels(bfo_engine *e, int io, int n_phys, const int virt2phys[]);
+void bfo_engine_set_delay(bfo_engine *e, int io, int virt_channel, int delay);
+void bfo_engine_set_maxdelay(bfo_engine *e, int io, int virt_channel, int maxdelay);
+void bfo_engine_set_mute(bfo_engine *e, int io, int virt_channel, int muted);
 /* load_coeff, bfconf.c:1867-2030: split n_taps into n_blocks partitions of L
    (n_blocks <= 0: ceil(n_taps / L), capped to N).  Returns coeff index or -1. */
 int bfo_engine_add_coeff(bfo_engine *e, const void *taps, int n_taps, double scale,

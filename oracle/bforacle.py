@@ -114,6 +114,9 @@ def lib():
         L.bfo_engine_set_format.argtypes = [vp, ci, ci, C.POINTER(Format)]
         L.bfo_engine_set_safety_limit.argtypes = [vp, cd]
         L.bfo_engine_enable_dither.argtypes = [vp, C.POINTER(ci), ci, ci, ci]
+        L.bfo_engine_map_channels.argtypes = [vp, ci, ci, C.POINTER(ci)]
+        for f in ("bfo_engine_set_delay", "bfo_engine_set_maxdelay", "bfo_engine_set_mute"):
+            getattr(L, f).argtypes = [vp, ci, ci, ci]
         L.bfo_engine_add_coeff.argtypes = [vp, vp, ci, cd, ci]
         ip, dp = C.POINTER(ci), C.POINTER(cd)
         L.bfo_engine_add_filter.argtypes = [vp, ci, ip, dp, ci, ip, dp, ci, ip, dp, ci, ci, ci]
@@ -272,6 +275,31 @@ class Engine:
 
     def set_safety_limit(self, v):
         lib().bfo_engine_set_safety_limit(self.h, v)
+
+    def map_channels(self, io, virt2phys):
+        """N:1 virtual -> physical mapping; afterwards formats address physical channels"""
+        n_phys = max(virt2phys) + 1
+        if not lib().bfo_engine_map_channels(self.h, io, n_phys, _iarr(list(virt2phys))):
+            raise ValueError("bad channel mapping")
+        if io == 0:
+            self.n_phys_in = n_phys
+        else:
+            self.n_phys_out = n_phys
+
+    def set_interleaved_phys(self, io, name, n_phys):
+        for c, f in enumerate(interleaved_formats(name, n_phys)):
+            self.set_format(io, c, f)
+        if io == 1:
+            self.out_bytes = n_phys * self.L * SAMPLE_FORMATS[name][0]
+
+    def set_delay(self, io, ch, delay):
+        lib().bfo_engine_set_delay(self.h, io, ch, delay)
+
+    def set_maxdelay(self, io, ch, maxdelay):
+        lib().bfo_engine_set_maxdelay(self.h, io, ch, maxdelay)
+
+    def set_mute(self, io, ch, muted):
+        lib().bfo_engine_set_mute(self.h, io, ch, int(muted))
 
     def enable_dither(self, channels, sample_rate, max_size=0):
         return lib().bfo_engine_enable_dither(self.h, _iarr(channels), len(channels),

@@ -164,3 +164,51 @@ def test_nan_and_safety_limit_are_reported():
     assert e.block(x)[0] == 2                   # reference: bf_exit (real2raw.h:32-41)
     x[5] = np.nan
     assert e.block(x)[0] == 1                   # reference: abort() (real2raw.h:24-31)
+
+
+def test_virtual_channel_mapping_delay_and_mute():
+    """bench4-style `mapping`: two virtual inputs fed by one physical input (own delays), two
+    virtual outputs mixed into one physical output (own delays, one muted for a while) --
+    bfrun.c:1509-1531 and :1938-2003; dirac filters, so the model is shifts and sums"""
+    L, N = 64, 2
+    e = bo.Engine(L, N, 8, 3, 3)
+    e.map_channels(0, [0, 0, 1])            # virtual inputs 0,1 <- physical 0; 2 <- physical 1
+    e.map_channels(1, [0, 0, 1])            # virtual outputs 0,1 -> physical 0; 2 -> physical 1
+    e.set_interleaved_phys(0, "FLOAT64_LE", 2)
+    e.set_interleaved_phys(1, "FLOAT64_LE", 2)
+    for v in range(3):
+        e.add_filter(in_ch=[v], out_ch=[v], coeff=-1)
+    din, dout = [5, 70, 0], [3, 100, 0]
+    for v in range(3):
+        e.set_delay(0, v, din[v]); e.set_maxdelay(0, v, -1)
+        e.set_delay(1, v, dout[v]); e.set_maxdelay(1, v, -1)
+    nblk = 12
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((nblk * L, 2))
+    y = []
+    for b in range(nblk):
+        e.set_mute(1, 1, 3 <= b < 6)        # virtual output 1 muted during blocks 3..5
+        e.set_mute(0, 0, b == 8)            # virtual input 0 muted in block 8
+        st, raw = e.block(x[b * L:(b + 1) * L])
+        assert st == 0
+        y.append(raw.view(np.float64).reshape(L, 2))
+    y = np.concatenate(y)
+
+    def shift(sig, d):
+        return np.concatenate([np.zeros(d), sig[:len(sig) - d]])
+    xin0 = x[:, 0].copy()
+    v0_in = xin0.copy()
+    # a muted input block is zeroed instead of passing through the delay line; the line itself
+    # is not advanced (bfrun.c:1510-1524), so the next block continues where it stopped
+    v0 = np.concatenate([shift(np.concatenate([xin0[:8 * L], xin0[9 * L:]]), din[0])[:8 * L],
+                         np.zeros(L),
+                         shift(np.concatenate([xin0[:8 * L], xin0[9 * L:]]), din[0])[8 * L:]])[:nblk * L]
+    v1 = shift(x[:, 0], din[1])
+    o0, o1 = shift(v0, dout[0]), shift(v1, dout[1])      # the output delay line always runs
+    mute1 = np.zeros(nblk * L, bool)
+    mute1[3 * L:6 * L] = True
+    want0 = o0 + np.where(mute1, 0.0, o1)
+    assert np.abs(y[:, 0] - want0).max() < 1e-12
+    assert np.abs(y[:, 1] - x[:, 1]).max() < 1e-12       # the 1:1 channel is untouched
+    # the overflow struct of a physical output is shared by its virtual channels (:1999-2001)
+    assert e.overflow(0).astuple() == e.overflow(1).astuple()
