@@ -83,6 +83,9 @@ def lib():
     L.bfhip_engine_destroy.argtypes = [vp]
     L.bfhip_engine_set_format.argtypes = [vp, ci, ci, C.POINTER(Format)]
     L.bfhip_engine_set_safety_limit.argtypes = [vp, cd]
+    L.bfhip_engine_map_channels.argtypes = [vp, ci, ci, ip]
+    for f in ("bfhip_engine_set_delay", "bfhip_engine_set_maxdelay", "bfhip_engine_set_mute"):
+        getattr(L, f).argtypes = [vp, ci, ci, ci]
     L.bfhip_engine_enable_dither.argtypes = [vp, ip, ci, ci, ci]
     L.bfhip_engine_add_coeff.argtypes = [vp, vp, ci, cd, ci]
     L.bfhip_engine_add_coeff_dev.argtypes = [vp, vp, ci, cd, ci]
@@ -180,6 +183,27 @@ class Engine:
 
     def set_safety_limit(self, v):
         _check(lib().bfhip_engine_set_safety_limit(self.h, v))
+
+    def map_channels(self, io, virt2phys):
+        _check(lib().bfhip_engine_map_channels(self.h, io, max(virt2phys) + 1, _iarr(list(virt2phys))))
+
+    def set_interleaved_phys(self, io, name, n_phys):
+        for c, f in enumerate(interleaved_formats(name, n_phys)):
+            self.set_format(io, c, f)
+        nbytes = n_phys * self.L * SAMPLE_FORMATS[name][0]
+        if io == IN:
+            self.in_bytes = nbytes
+        else:
+            self.out_bytes = nbytes
+
+    def set_delay(self, io, ch, delay):
+        _check(lib().bfhip_engine_set_delay(self.h, io, ch, delay))
+
+    def set_maxdelay(self, io, ch, maxdelay):
+        _check(lib().bfhip_engine_set_maxdelay(self.h, io, ch, maxdelay))
+
+    def set_mute(self, io, ch, muted):
+        _check(lib().bfhip_engine_set_mute(self.h, io, ch, int(muted)))
 
     def enable_dither(self, channels, sample_rate, max_size=0):
         _check(lib().bfhip_engine_enable_dither(self.h, _iarr(list(channels)), len(channels),

@@ -68,6 +68,89 @@ struct Filter {
 
 constexpr int MAX_TIMED = 4096;
 
+// Host mirror of the reference's integer delay buffer (delay.c:29-45, 229-340, 346-411): same
+// state variables, same decisions; the byte moves themselves are emitted as ByteOps that a
+// device kernel executes on buffers in HBM.  Contiguous buffers only (how filter_process() uses
+// it for channels that share a physical channel, bfrun.c:1517-1521, 1948).
+struct DelayLine {
+    int F = 0, ss = 0, maxdelay = 0, curdelay = 0, cur = 0, n_full = 0, n_full_cap = 0, n_rest = 0;
+    uint8_t *arena = nullptr;
+    std::vector<uint8_t *> full;
+    uint8_t *rest = nullptr, *shrt[2] = {nullptr, nullptr}, *tmp = nullptr;
+
+    size_t frag() const { return (size_t)F * ss; }
+
+    int init(int fragment, int initdelay, int maxd, int sample_size) {
+        F = fragment; ss = sample_size;
+        int delay = maxd <= 0 ? initdelay : maxd;                      // delay.c:357-360
+        if (maxd >= 0 && delay > maxd) delay = initdelay = maxd;
+        curdelay = initdelay; maxdelay = maxd;
+        n_full_cap = delay > F ? delay / F + 1 : 0;
+        const size_t total = (size_t)(n_full_cap + 4) * frag();
+        if (hipMalloc((void **)&arena, total) != hipSuccess) return BFHIP_ENOMEM;
+        if (hipMemset(arena, 0, total) != hipSuccess) return BFHIP_EHIP;
+        uint8_t *p = arena;
+        for (int i = 0; i < n_full_cap; i++) { full.push_back(p); p += frag(); }
+        rest = p; p += frag();
+        shrt[0] = p; p += frag();
+        shrt[1] = p; p += frag();
+        tmp = p;
+        if (delay == 0) return BFHIP_OK;
+        if (delay <= F) { n_rest = initdelay; return BFHIP_OK; }       // :365-374
+        n_rest = initdelay % F;
+        n_full = initdelay / F + 1;
+        if (n_full == 1) n_full = 0;
+        return BFHIP_OK;
+    }
+
+    static void op(std::vector<ByteOp> &ops, uint8_t *dst, const uint8_t *src, size_t n) {
+        if (n == 0) return;
+        ByteOp o; o.dst = dst; o.src = src; o.n = (unsigned int)n; o.pad = 0;
+        ops.push_back(o);
+    }
+
+    void retarget(int newdelay, std::vector<ByteOp> &ops) {           // change_delay, :283-318
+        if (newdelay == curdelay || newdelay > maxdelay) return;
+        if (newdelay <= F) {
+            n_rest = newdelay;
+            if (curdelay > F || curdelay < newdelay) {
+                op(ops, shrt[0], nullptr, (size_t)newdelay * ss);
+                op(ops, shrt[1], nullptr, (size_t)newdelay * ss);
+            }
+            n_full = 0; cur = 0; curdelay = newdelay;
+            return;
+        }
+        n_rest = newdelay % F;
+        n_full = newdelay / F + 1;
+        if (curdelay < newdelay) {
+            for (int i = 0; i < n_full; i++) op(ops, full[i], nullptr, frag());
+            if (n_rest != 0) op(ops, rest, nullptr, (size_t)n_rest * ss);
+        }
+        cur = 0; curdelay = newdelay;
+    }
+
+    void update(uint8_t *buf, int delay, std::vector<ByteOp> &ops) {  // delay_update, :320-340
+        retarget(delay, ops);
+        const size_t rr = (size_t)n_rest * ss;
+        if (n_full > 0) {                                              // update_delay_buffer
+            uint8_t *last = cur == n_full - 1 ? full[0] : full[cur + 1];
+            op(ops, full[cur], buf, frag());
+            if (rr != 0) {
+                op(ops, buf, rest, rr);
+                op(ops, rest, last + (frag() - rr), rr);
+            }
+            op(ops, buf + rr, last, frag() - rr);
+            if (++cur == n_full) cur = 0;
+        } else if (n_rest > 0) {                                       // update_delay_short_buffer
+            op(ops, shrt[cur], buf + (frag() - rr), rr);
+            op(ops, tmp, buf, frag() - rr);                            // shift_samples via a
+            op(ops, buf + rr, tmp, frag() - rr);                       // scratch copy
+            cur = !cur;
+            op(ops, buf, shrt[cur], rr);
+        }
+    }
+};
+
 }  // namespace
 
 struct bfhip_engine {
@@ -130,6 +213,19 @@ struct bfhip_engine {
     std::vector<LevelJobs> level_jobs;
     size_t src_off = 0;
     bool any_fading = false;
+
+    // N:1 virtual -> physical channels (bfconf->virt2phys): fmt[] is indexed by PHYSICAL channel
+    int n_phys[2] = {0, 0};
+    std::vector<int> v2p[2], n_vpp[2], vdelay[2], vmaxdelay[2], vmuted[2];
+    std::vector<DelayLine> vline[2];
+    std::vector<int> vin_list;             // virtual inputs that share a physical one
+    std::vector<std::vector<int>> vout_groups;   // members of every shared physical output
+    uint8_t *d_incopy = nullptr;           // [vin_list.size()][L * 8]
+    void *d_vjobs = nullptr;               // per-block job/op tables (device)
+    void *h_vjobs = nullptr;               // pinned staging ring
+    size_t vjobs_slot = 0;
+    int vjobs_turn = 0;
+    bool has_vchan = false;
 
     // HP-TPDF dither (dither.c, dither.h)
     std::vector<int> dither_channels;      // output channel of each dither slot
@@ -385,7 +481,7 @@ int build_plan_t(bfhip_engine *e) {
             for (size_t i = 0; i < f.in_ch.size(); i++) {
                 MixSrc<T> m;
                 m.spec = (const c2<T> *)e->d_ring + (size_t)f.in_ch[i] * e->R * L;
-                m.scale = (T)(f.in_scale[i] * e->fmt[0][f.in_ch[i]].scale);      // bfrun.c:1641
+                m.scale = (T)(f.in_scale[i] * e->fmt[0][e->v2p[0][f.in_ch[i]]].scale);      // bfrun.c:1641 (virtscales)
                 m.R = e->R;
                 srcs.push_back(m);
             }
@@ -404,7 +500,7 @@ int build_plan_t(bfhip_engine *e) {
             const int ch = f.in_ch[0];
             ring = (const c2<T> *)e->d_ring + (size_t)ch * e->R * L;
             ring_id = ch; rdelay = delay;
-            rscale = f.in_scale[0] * e->fmt[0][ch].scale;                         // bfrun.c:1664
+            rscale = f.in_scale[0] * e->fmt[0][e->v2p[0][ch]].scale;                         // bfrun.c:1664
         }
         {
             auto &u = ring_used[ring_id];
@@ -438,7 +534,7 @@ int build_plan_t(bfhip_engine *e) {
         for (size_t oi = 0; oi < f.out_ch.size(); oi++) {
             const int o = f.out_ch[oi];
             const int g = o / OG, j = o % OG;
-            const double s_out = f.out_scale[oi] / e->fmt[1][o].scale;            // bfrun.c:1850
+            const double s_out = f.out_scale[oi] / e->fmt[1][e->v2p[1][o]].scale;            // bfrun.c:1850
             const std::pair<long, int> key = needY ? std::make_pair((long)(I + F + fi), 0)
                                                    : std::make_pair(ring_id, rdelay);
             auto &slots = index[g][key];
@@ -613,7 +709,7 @@ int build_plan_t(bfhip_engine *e) {
     for (auto &kv : ring_used) for (char u : kv.second) bytes_ring += u ? C : 0;
     double raw = 0;
     for (int io = 0; io < 2; io++)
-        for (auto &f : e->fmt[io]) raw += (double)L * f.bytes;
+        for (int c = 0; c < e->n_phys[io]; c++) raw += (double)L * e->fmt[io][c].bytes;
     e->alg_bytes_mac = bytes_H + bytes_ring + C * O;
     e->alg_bytes_total = e->alg_bytes_mac + C * (I + e->n_owners) + raw;
     e->plan_dirty = false;
@@ -624,9 +720,10 @@ int build_plan(bfhip_engine *e) {
     return e->rs == 4 ? build_plan_t<float>(e) : build_plan_t<double>(e);
 }
 
-size_t raw_extent(const std::vector<bfhip_format> &v, int L) {
+size_t raw_extent(const std::vector<bfhip_format> &v, int n, int L) {
     size_t m = 0;
-    for (auto &f : v) {
+    for (int i = 0; i < n; i++) {
+        const bfhip_format &f = v[i];
         const size_t end = (size_t)f.byte_offset + ((size_t)(L - 1) * f.sample_spacing + 1) * f.bytes;
         m = std::max(m, end);
     }
@@ -637,6 +734,7 @@ DevFormat to_dev(const bfhip_format &f) {
     DevFormat d;
     d.isfloat = f.isfloat; d.swap = f.swap; d.bytes = f.bytes; d.sbytes = f.sbytes;
     d.sample_spacing = f.sample_spacing; d.byte_offset = f.byte_offset;
+    d.alt = nullptr;
     return d;
 }
 
@@ -646,8 +744,20 @@ double overflow_max(const bfhip_format &f) {             // bfrun.c:2270-2277
 
 int upload_formats(bfhip_engine *e) {
     for (int io = 0; io < 2; io++) {
+        // the device tables are indexed by VIRTUAL channel and hold the physical channel's format
         std::vector<DevFormat> d;
-        for (auto &f : e->fmt[io]) d.push_back(to_dev(f));
+        for (int v = 0; v < e->n_ch[io]; v++) {
+            DevFormat f = to_dev(e->fmt[io][e->v2p[io][v]]);
+            if (io == 0 && e->n_vpp[0][e->v2p[0][v]] > 1) {
+                // a private, delayed copy of the samples (bfrun.c:1509-1531), contiguous
+                size_t k = 0;
+                while (e->vin_list[k] != v) k++;
+                f.alt = e->d_incopy + k * (size_t)e->L * 8;
+                f.sample_spacing = 1;
+                f.byte_offset = 0;
+            }
+            d.push_back(f);
+        }
         if (!d.empty()) HIPCHK(hipMemcpy(e->d_fmt[io], d.data(), d.size() * sizeof(DevFormat), hipMemcpyHostToDevice));
     }
     return BFHIP_OK;
@@ -675,7 +785,74 @@ int ensure_ready(bfhip_engine *e) {
     return BFHIP_OK;
 }
 
+// N:1 inputs: gather + mute + integer delay into the private copies K1 reads (bfrun.c:1509-1531)
+int do_vin(bfhip_engine *e, const void *rawin_dev) {
+    if (e->vin_list.empty()) return BFHIP_OK;
+    std::vector<VInJob> jobs;
+    std::vector<ByteOp> ops;
+    for (size_t k = 0; k < e->vin_list.size(); k++) {
+        const int v = e->vin_list[k];
+        const bfhip_format &f = e->fmt[0][e->v2p[0][v]];
+        VInJob j;
+        j.copy = e->d_incopy + k * (size_t)e->L * 8;
+        j.byte_offset = f.byte_offset; j.sample_spacing = f.sample_spacing; j.bytes = f.bytes;
+        j.muted = e->vmuted[0][v];
+        j.ops_off = (int)ops.size();
+        if (!j.muted) e->vline[0][v].update(j.copy, e->vdelay[0][v], ops);   // not advanced when muted
+        j.n_ops = (int)ops.size() - j.ops_off;
+        jobs.push_back(j);
+    }
+    const size_t jb = jobs.size() * sizeof(VInJob), ob = ops.size() * sizeof(ByteOp);
+    if (jb + ob > e->vjobs_slot) return fail(BFHIP_ESTATE, "virtual-channel job table overflow");
+    unsigned char *dev = (unsigned char *)e->d_vjobs;
+    HIPCHK(hipMemcpyAsync(dev, jobs.data(), jb, hipMemcpyHostToDevice, e->ls));
+    if (ob) HIPCHK(hipMemcpyAsync(dev + jb, ops.data(), ob, hipMemcpyHostToDevice, e->ls));
+    hipLaunchKernelGGL(vchan_in_kernel<0>, dim3((unsigned)jobs.size()), dim3(256), 0, e->ls,
+                       (const VInJob *)dev, (const ByteOp *)(dev + jb), (const uint8_t *)rawin_dev, e->L);
+    HIPCHK(hipGetLastError());
+    return BFHIP_OK;
+}
+
+// N:1 outputs: integer delay of every member, mix of the un-muted ones, one requantisation
+// (bfrun.c:1938-2003); runs after K3 has left the members' time samples in d_timeout
+int do_vout(bfhip_engine *e, void *rawout_dev) {
+    if (e->vout_groups.empty()) return BFHIP_OK;
+    std::vector<VOutJob> jobs;
+    std::vector<VOutMember> mem;
+    std::vector<ByteOp> ops;
+    for (auto &g : e->vout_groups) {
+        VOutJob j;
+        j.first_member = (int)mem.size(); j.n_members = (int)g.size(); j.fmt_channel = g[0]; j.pad = 0;
+        for (int v : g) {
+            VOutMember m;
+            m.channel = v; m.muted = e->vmuted[1][v]; m.ops_off = (int)ops.size();
+            uint8_t *row = (uint8_t *)e->d_timeout + (size_t)v * e->L * e->rs;
+            e->vline[1][v].update(row, e->vdelay[1][v], ops);        // always advanced (:1948)
+            m.n_ops = (int)ops.size() - m.ops_off;
+            mem.push_back(m);
+        }
+        jobs.push_back(j);
+    }
+    const size_t jb = jobs.size() * sizeof(VOutJob), mb = mem.size() * sizeof(VOutMember), ob = ops.size() * sizeof(ByteOp);
+    if (jb + mb + ob > e->vjobs_slot) return fail(BFHIP_ESTATE, "virtual-channel job table overflow");
+    unsigned char *dev = (unsigned char *)e->d_vjobs + e->vjobs_slot;      // second half: output side
+    HIPCHK(hipMemcpyAsync(dev, jobs.data(), jb, hipMemcpyHostToDevice, e->ls));
+    HIPCHK(hipMemcpyAsync(dev + jb, mem.data(), mb, hipMemcpyHostToDevice, e->ls));
+    if (ob) HIPCHK(hipMemcpyAsync(dev + jb + mb, ops.data(), ob, hipMemcpyHostToDevice, e->ls));
+    if (e->rs == 4)
+        hipLaunchKernelGGL(vchan_out_kernel<float>, dim3((unsigned)jobs.size()), dim3(256), 0, e->ls,
+                           (const VOutJob *)dev, (const VOutMember *)(dev + jb), (const ByteOp *)(dev + jb + mb),
+                           (float *)e->d_timeout, e->d_fmt[1], e->d_over, (uint8_t *)rawout_dev, e->L, e->safety_limit, e->d_status);
+    else
+        hipLaunchKernelGGL(vchan_out_kernel<double>, dim3((unsigned)jobs.size()), dim3(256), 0, e->ls,
+                           (const VOutJob *)dev, (const VOutMember *)(dev + jb), (const ByteOp *)(dev + jb + mb),
+                           (double *)e->d_timeout, e->d_fmt[1], e->d_over, (uint8_t *)rawout_dev, e->L, e->safety_limit, e->d_status);
+    HIPCHK(hipGetLastError());
+    return BFHIP_OK;
+}
+
 int do_inputs(bfhip_engine *e, const void *rawin_dev) {
+    { int rv = do_vin(e, rawin_dev); if (rv != BFHIP_OK) return rv; }
     hipError_t err = hipSuccess;
     const int slot = (int)(e->blockcounter % (unsigned int)e->R);
     DISPATCH(launch_fft_in, e, (const uint8_t *)rawin_dev, slot, &err);
@@ -704,9 +881,11 @@ int do_outputs(bfhip_engine *e, const void *Zp, size_t chunk_stride, int n_chunk
                int count, void *rawout_dev) {
     hipError_t err = hipSuccess;
     if (count <= 0) return BFHIP_OK;
+    if (!e->vout_groups.empty() && (first != 0 || count != e->n_ch[1]))
+        return fail(BFHIP_EINVAL, "outputs that share a physical channel cannot be split over several calls");
     DISPATCH(launch_ifft_out, e, Zp, chunk_stride, n_chunks, first, count, (uint8_t *)rawout_dev, &err);
     if (err != hipSuccess) return fail(BFHIP_EHIP, "ifft_out launch: %s", hipGetErrorString(err));
-    return BFHIP_OK;
+    return do_vout(e, rawout_dev);
 }
 
 void advance(bfhip_engine *e) {
@@ -759,6 +938,15 @@ bfhip_engine *bfhip_engine_create(int device, int length, int n_blocks, int real
             f.sample_spacing = 1; f.byte_offset = c * length * realsize;
         }
     }
+    for (int io = 0; io < 2; io++) {
+        e->n_phys[io] = e->n_ch[io];
+        e->v2p[io].resize(e->n_ch[io]);
+        for (int c = 0; c < e->n_ch[io]; c++) e->v2p[io][c] = c;
+        e->n_vpp[io].assign(e->n_ch[io], 1);
+        e->vdelay[io].assign(e->n_ch[io], 0);
+        e->vmaxdelay[io].assign(e->n_ch[io], 0);
+        e->vmuted[io].assign(e->n_ch[io], 0);
+    }
     bool ok = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) == hipSuccess;
     e->own_stream = ok;
     // twiddles exp(-2 pi i m / (2L)), computed in double
@@ -787,6 +975,9 @@ void bfhip_engine_destroy(bfhip_engine *e) {
     (void)sync_all(e);
     for (auto &c : e->coeffs) if (c.d_H) (void)hipFree(c.d_H);
     for (void *p : e->promoted) if (p) (void)hipFree(p);
+    for (int io = 0; io < 2; io++) for (auto &dl : e->vline[io]) if (dl.arena) (void)hipFree(dl.arena);
+    if (e->d_incopy) (void)hipFree(e->d_incopy);
+    if (e->d_vjobs) (void)hipFree(e->d_vjobs);
     if (e->d_Zp2) (void)hipFree(e->d_Zp2);
     for (int i = 0; i < 2; i++) {
         if (e->ev_in[i]) (void)hipEventDestroy(e->ev_in[i]);
@@ -806,7 +997,7 @@ void bfhip_engine_destroy(bfhip_engine *e) {
 }
 
 int bfhip_engine_set_format(bfhip_engine *e, int io, int ch, const bfhip_format *bf) {
-    if (!e || !bf || io < 0 || io > 1 || ch < 0 || ch >= e->n_ch[io]) return fail(BFHIP_EINVAL, "set_format: bad argument");
+    if (!e || !bf || io < 0 || io > 1 || ch < 0 || ch >= e->n_phys[io]) return fail(BFHIP_EINVAL, "set_format: bad argument");
     if (!check_format(bf)) return fail(BFHIP_EINVAL, "Sample byte size %d is not supported.", bf->bytes);
     if (e->finalized) return fail(BFHIP_ESTATE, "set_format after finalize");
     e->fmt[io][ch] = *bf;
@@ -816,6 +1007,42 @@ int bfhip_engine_set_format(bfhip_engine *e, int io, int ch, const bfhip_format 
 int bfhip_engine_set_safety_limit(bfhip_engine *e, double limit) {
     if (!e) return fail(BFHIP_EINVAL, "null engine");
     e->safety_limit = limit;
+    return BFHIP_OK;
+}
+
+int bfhip_engine_map_channels(bfhip_engine *e, int io, int n_phys, const int virt2phys[]) {
+    if (!e || io < 0 || io > 1 || !virt2phys || n_phys < 1 || n_phys > e->n_ch[io]) return fail(BFHIP_EINVAL, "map_channels: bad argument");
+    if (e->finalized) return fail(BFHIP_ESTATE, "map_channels after finalize");
+    std::vector<int> cnt(n_phys, 0);
+    for (int v = 0; v < e->n_ch[io]; v++) {
+        if (virt2phys[v] < 0 || virt2phys[v] >= n_phys) return fail(BFHIP_EINVAL, "map_channels: physical channel %d", virt2phys[v]);
+        // bfrun.c:1981 counts the members of a physical output as they come: they must be adjacent
+        if (v > 0 && virt2phys[v] < virt2phys[v - 1]) return fail(BFHIP_EINVAL, "map_channels: virtual channels of a physical channel must be consecutive");
+        cnt[virt2phys[v]]++;
+    }
+    for (int c = 0; c < n_phys; c++) if (cnt[c] == 0) return fail(BFHIP_EINVAL, "map_channels: physical channel %d unused", c);
+    e->n_phys[io] = n_phys;
+    e->v2p[io].assign(virt2phys, virt2phys + e->n_ch[io]);
+    e->n_vpp[io] = cnt;
+    return BFHIP_OK;
+}
+
+int bfhip_engine_set_delay(bfhip_engine *e, int io, int ch, int delay) {
+    if (!e || io < 0 || io > 1 || ch < 0 || ch >= e->n_ch[io] || delay < 0) return fail(BFHIP_EINVAL, "set_delay: bad argument");
+    e->vdelay[io][ch] = delay;
+    return BFHIP_OK;
+}
+
+int bfhip_engine_set_maxdelay(bfhip_engine *e, int io, int ch, int maxdelay) {
+    if (!e || io < 0 || io > 1 || ch < 0 || ch >= e->n_ch[io]) return fail(BFHIP_EINVAL, "set_maxdelay: bad argument");
+    if (e->finalized) return fail(BFHIP_ESTATE, "set_maxdelay after finalize");
+    e->vmaxdelay[io][ch] = maxdelay;
+    return BFHIP_OK;
+}
+
+int bfhip_engine_set_mute(bfhip_engine *e, int io, int ch, int muted) {
+    if (!e || io < 0 || io > 1 || ch < 0 || ch >= e->n_ch[io]) return fail(BFHIP_EINVAL, "set_mute: bad argument");
+    e->vmuted[io][ch] = muted != 0;
     return BFHIP_OK;
 }
 
@@ -1061,6 +1288,7 @@ int bfhip_engine_finalize(bfhip_engine *e) {
         }
         e->pipelined = bytes / 6.4e12 < 100e-6;
         if (const char *env = getenv("BFHIP_OVERLAP")) e->pipelined = atoi(env) != 0;
+        for (int io = 0; io < 2; io++) for (int c : e->n_vpp[io]) if (c > 1) e->pipelined = false;   // one job table per side
     }
     e->R = e->pipelined ? e->N + 1 : e->N;
     const size_t ring_b = (size_t)e->n_ch[0] * e->R * L * e->csize();
@@ -1069,13 +1297,54 @@ int bfhip_engine_finalize(bfhip_engine *e) {
     HIPCHK(hipMemset(e->d_prev, 0, prev_b));       // bfrun.c:1388: everything starts zeroed
     HIPCHK(hipMemset(e->d_ring, 0, ring_b));
     for (int io = 0; io < 2; io++) HIPCHK(hipMalloc((void **)&e->d_fmt[io], e->n_ch[io] * sizeof(DevFormat)));
+    // channels that share a physical channel: private copies, delay lines, job tables
+    {
+        e->vin_list.clear(); e->vout_groups.clear();
+        for (int v = 0; v < e->n_ch[0]; v++) if (e->n_vpp[0][e->v2p[0][v]] > 1) e->vin_list.push_back(v);
+        for (int v = 0; v < e->n_ch[1]; v++) {
+            if (e->n_vpp[1][e->v2p[1][v]] <= 1) continue;
+            if (e->vout_groups.empty() || e->v2p[1][e->vout_groups.back()[0]] != e->v2p[1][v]) e->vout_groups.push_back({});
+            e->vout_groups.back().push_back(v);
+        }
+        e->has_vchan = !e->vin_list.empty() || !e->vout_groups.empty();
+        if (e->has_vchan) {
+            if (!e->dither_channels.empty()) return fail(BFHIP_EINVAL, "dither on outputs that share a physical channel is not supported");
+            size_t n_ops_max = 0;
+            e->vline[0].assign(e->n_ch[0], DelayLine());
+            e->vline[1].assign(e->n_ch[1], DelayLine());
+            for (int v : e->vin_list) {
+                int rr = e->vline[0][v].init(e->L, e->vdelay[0][v], e->vmaxdelay[0][v], e->fmt[0][e->v2p[0][v]].bytes);
+                if (rr != BFHIP_OK) return fail(rr, "delay buffer allocation failed");
+                n_ops_max += e->vline[0][v].n_full_cap + 10;
+            }
+            for (auto &g : e->vout_groups) for (int v : g) {
+                int rr = e->vline[1][v].init(e->L, e->vdelay[1][v], e->vmaxdelay[1][v], e->rs);
+                if (rr != BFHIP_OK) return fail(rr, "delay buffer allocation failed");
+                n_ops_max += e->vline[1][v].n_full_cap + 10;
+            }
+            if (!e->vin_list.empty()) {
+                HIPCHK(hipMalloc((void **)&e->d_incopy, e->vin_list.size() * (size_t)e->L * 8));
+                HIPCHK(hipMemset(e->d_incopy, 0, e->vin_list.size() * (size_t)e->L * 8));
+            }
+            e->vjobs_slot = (n_ops_max + 8) * sizeof(ByteOp) + (e->n_ch[0] + e->n_ch[1] + 8) * 64;
+            HIPCHK(hipMalloc(&e->d_vjobs, 2 * e->vjobs_slot));
+            if (!e->vout_groups.empty()) {
+                std::vector<unsigned char> skip(e->n_ch[1], 0);
+                for (auto &g : e->vout_groups) for (int v : g) skip[v] = 1;
+                HIPCHK(hipMalloc((void **)&e->d_skip_quant, skip.size()));
+                HIPCHK(hipMemcpy(e->d_skip_quant, skip.data(), skip.size(), hipMemcpyHostToDevice));
+                HIPCHK(hipMalloc(&e->d_timeout, (size_t)e->n_ch[1] * e->L * e->rs));
+                HIPCHK(hipMemset(e->d_timeout, 0, (size_t)e->n_ch[1] * e->L * e->rs));
+            }
+        }
+    }
     int r = upload_formats(e);
     if (r != BFHIP_OK) return r;
     HIPCHK(hipMalloc((void **)&e->d_over, e->n_ch[1] * sizeof(DevOverflow)));
     HIPCHK(hipMalloc((void **)&e->d_status, sizeof(int)));
     HIPCHK(hipMemset(e->d_status, 0, sizeof(int)));
-    e->raw_bytes[0] = raw_extent(e->fmt[0], e->L);
-    e->raw_bytes[1] = raw_extent(e->fmt[1], e->L);
+    e->raw_bytes[0] = raw_extent(e->fmt[0], e->n_phys[0], e->L);
+    e->raw_bytes[1] = raw_extent(e->fmt[1], e->n_phys[1], e->L);
     HIPCHK(hipMalloc((void **)&e->d_rawin, e->raw_bytes[0]));
     HIPCHK(hipMalloc((void **)&e->d_rawout, e->raw_bytes[1]));
     HIPCHK(hipMemset(e->d_rawout, 0, e->raw_bytes[1]));
@@ -1144,7 +1413,7 @@ static int promote_filter(bfhip_engine *e, int fi) {
     HIPCHK(hipMemsetAsync(ring, 0, bytes, e->stream));
     const int ch = f.in_ch[0];
     const int delay = clamp_delay(e, f.delayblocks);
-    const double sc = f.in_scale[0] * e->fmt[0][ch].scale;
+    const double sc = f.in_scale[0] * e->fmt[0][e->v2p[0][ch]].scale;
     const int n_valid = (int)std::min<unsigned long long>(e->blocks_done, (unsigned long long)e->N);
     if (n_valid > 0) {
         const dim3 grid((e->L + 255) / 256, n_valid);
@@ -1233,7 +1502,7 @@ int bfhip_engine_outputs_inputs_dev(bfhip_engine *e, const void *z_dev, int firs
     int r = ensure_ready(e);
     if (r != BFHIP_OK) return r;
     if (first < 0 || count < 0 || first + count > e->n_ch[1]) return fail(BFHIP_EINVAL, "outputs: channel range");
-    if (!e->dither_channels.empty() || count == 0) {
+    if (!e->dither_channels.empty() || e->has_vchan || count == 0) {
         // the dither pass follows the inverse transforms: keep the two launches apart
         if ((r = bfhip_engine_outputs_dev(e, z_dev, first, count, rawout_dev)) != BFHIP_OK) return r;
         return bfhip_engine_inputs_dev(e, rawin_dev);
@@ -1343,7 +1612,7 @@ int bfhip_engine_reset_overflow(bfhip_engine *e) {
     std::vector<DevOverflow> v(e->n_ch[1]);
     for (int c = 0; c < e->n_ch[1]; c++) {
         memset(&v[c], 0, sizeof(DevOverflow));
-        v[c].max = overflow_max(e->fmt[1][c]);
+        v[c].max = overflow_max(e->fmt[1][e->v2p[1][c]]);
     }
     { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
     HIPCHK(hipMemcpy(e->d_over, v.data(), v.size() * sizeof(DevOverflow), hipMemcpyHostToDevice));

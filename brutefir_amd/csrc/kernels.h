@@ -25,6 +25,8 @@ namespace bfhip {
 struct DevFormat {          // bfhip_format, device copy
     int isfloat, swap, bytes, sbytes;
     int sample_spacing, byte_offset;
+    const uint8_t *alt;     // input side: read from here instead of the raw buffer (a virtual
+                            // channel's private, delayed copy: N:1 mapped inputs), else null
 };
 
 struct DevOverflow {        // struct bfoverflow (bfmod.h:99-104)
@@ -168,7 +170,7 @@ fft_in_body(int ch, unsigned char *smem, const uint8_t *__restrict__ raw, const 
     const int tid = threadIdx.x;
     const DevFormat f = fmt[ch];
     c2<T> *pv = reinterpret_cast<c2<T> *>(prev + (size_t)ch * L);
-    const uint8_t *base = raw + f.byte_offset;
+    const uint8_t *base = f.alt ? f.alt : raw + f.byte_offset;
     const size_t stride = (size_t)f.sample_spacing * f.bytes;
 
     TwRegs<T, LOG2L, NT> twr;
@@ -939,6 +941,150 @@ io_kernel(int n_k3,
                                 rawout, timeout, tw, safety_limit, status);
     else
         fft_in_body<T, LOG2L>((int)blockIdx.x - n_k3, smem, rawin, fmt_in, prev, ring, tw, R, slot);
+}
+
+// ------------------------------------------------------------------ N:1 virtual channels: delay, mute, mix
+
+// The reference's integer delay (delay.c:78-340) is a little machine of memcpy/memset between a
+// ring of whole-fragment buffers, a rest buffer and two short buffers; which copies happen
+// depends on the delay history.  The host mirrors that machine (DelayLine in bfhip.hip) and
+// emits, per update, the list of byte moves; the device only executes them, in order.
+struct ByteOp {
+    uint8_t *dst;
+    const uint8_t *src;     // null: zero fill
+    unsigned int n;
+    unsigned int pad;
+};
+
+__device__ __forceinline__ void run_byte_ops(const ByteOp *__restrict__ ops, int n_ops) {
+    for (int i = 0; i < n_ops; i++) {
+        const ByteOp op = ops[i];
+        __syncthreads();                       // previous op's stores are visible (global memory,
+        __threadfence_block();                 // same workgroup)
+        for (unsigned int b = threadIdx.x; b < op.n; b += blockDim.x) op.dst[b] = op.src ? op.src[b] : (uint8_t)0;
+    }
+    __syncthreads();
+    __threadfence_block();
+}
+
+// Input side (bfrun.c:1509-1531): one workgroup per virtual input that shares a physical one.
+// Gather its samples from the raw buffer into the private copy (or zero it when muted, in
+// which case the delay line is NOT advanced), then run the delay line's moves on the copy.
+struct VInJob {
+    uint8_t *copy;          // [L * bytes] private contiguous copy, what K1 then reads
+    int byte_offset, sample_spacing, bytes, muted;
+    int ops_off, n_ops;
+};
+
+template <int UNUSED>
+__global__ __launch_bounds__(256) void
+vchan_in_kernel(const VInJob *__restrict__ jobs, const ByteOp *__restrict__ ops,
+                const uint8_t *__restrict__ raw, int L) {
+    const VInJob job = jobs[blockIdx.x];
+    const unsigned int total = (unsigned int)L * job.bytes;
+    if (job.muted) {
+        for (unsigned int b = threadIdx.x; b < total; b += blockDim.x) job.copy[b] = 0;
+        return;
+    }
+    const size_t stride = (size_t)job.sample_spacing * job.bytes;
+    for (unsigned int b = threadIdx.x; b < total; b += blockDim.x) {
+        const unsigned int smp = b / job.bytes, k = b % job.bytes;
+        job.copy[b] = raw[job.byte_offset + smp * stride + k];
+    }
+    run_byte_ops(ops + job.ops_off, job.n_ops);
+}
+
+// Output side (bfrun.c:1938-2003): one workgroup per physical output that several virtual
+// outputs mix into.  Every member's time samples (from K3) go through its delay line; the
+// un-muted ones are added up in channel order (float adds, first one copied); the sum is
+// requantised once with the group's shared overflow struct, which is then copied to every
+// member.
+struct VOutMember { int channel, muted, ops_off, n_ops; };
+struct VOutJob { int first_member, n_members, fmt_channel, pad; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void
+vchan_out_kernel(const VOutJob *__restrict__ jobs, const VOutMember *__restrict__ members,
+                 const ByteOp *__restrict__ ops, T *__restrict__ samples /* [n_out][L] */,
+                 const DevFormat *__restrict__ fmt, DevOverflow *__restrict__ over,
+                 uint8_t *__restrict__ raw, int L, double safety_limit, int *__restrict__ status) {
+    __shared__ unsigned int red_n[4];
+    __shared__ int32_t red_i[4];
+    __shared__ double red_l[4];
+    __shared__ int red_s[4];
+    const VOutJob job = jobs[blockIdx.x];
+    const VOutMember *mem = members + job.first_member;
+    const int tid = threadIdx.x;
+    for (int m = 0; m < job.n_members; m++) run_byte_ops(ops + mem[m].ops_off, mem[m].n_ops);
+
+    const int last = mem[job.n_members - 1].channel;
+    const DevFormat f = fmt[job.fmt_channel];
+    DevOverflow of = over[last];
+    uint8_t *base = raw + f.byte_offset;
+    const size_t stride = (size_t)f.sample_spacing * f.bytes;
+    const int bits = f.sbytes << 3;
+    const int32_t imin = (int32_t)(-((uint64_t)1 << (bits - 1)));
+    const int32_t imax = (int32_t)(((uint64_t)1 << (bits - 1)) - 1);
+    const double rmin_i = (double)(T)imin, rmax_i = (double)(T)imax;
+    const T rmin_f = (T)(-of.max), rmax_f = (T)of.max;
+    unsigned int n_over = 0;
+    int32_t intlargest = of.intlargest;
+    double largest = of.largest;
+    int st = 0;
+    for (int n = tid; n < L; n += 256) {
+        T x = (T)0;
+        bool filled = false;
+        for (int m = 0; m < job.n_members; m++) {
+            if (mem[m].muted) continue;
+            const T v = samples[(size_t)mem[m].channel * L + n];
+            x = filled ? x + v : v;
+            filled = true;
+        }
+        uint8_t tb[8];
+        if (!isfinite(x)) { st |= 1; continue; }
+        if (safety_limit != 0.0 && ((double)x < -safety_limit * of.max || (double)x > safety_limit * of.max)) { st |= 2; continue; }
+        if (f.isfloat) {
+            if (x < (T)0) {
+                if (x < rmin_f) n_over++;
+                if ((double)x < -largest) largest = -(double)x;
+            } else {
+                if (x > rmax_f) n_over++;
+                if ((double)x > largest) largest = (double)x;
+            }
+            if (f.bytes == 4) {
+                const uint32_t u = __float_as_uint((float)x);
+                tb[0] = u & 0xff; tb[1] = (u >> 8) & 0xff; tb[2] = (u >> 16) & 0xff; tb[3] = u >> 24;
+            } else {
+                const uint64_t u = (uint64_t)__double_as_longlong((double)x);
+                for (int i = 0; i < 8; i++) tb[i] = (u >> (8 * i)) & 0xff;
+            }
+        } else {
+            const uint32_t u = (uint32_t)real2int_no_dither((double)x, rmin_i, rmax_i, imin, imax, n_over, intlargest, largest);
+            tb[0] = u & 0xff; tb[1] = (u >> 8) & 0xff; tb[2] = (u >> 16) & 0xff; tb[3] = u >> 24;
+        }
+        store_raw_bytes(base + (size_t)n * stride, tb, f.bytes, f.swap);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        n_over += __shfl_down(n_over, off);
+        const int32_t oi = __shfl_down(intlargest, off);
+        intlargest = oi > intlargest ? oi : intlargest;
+        const double ol = __shfl_down(largest, off);
+        largest = ol > largest ? ol : largest;
+        st |= __shfl_down(st, off);
+    }
+    if ((tid & 63) == 0) { red_n[tid >> 6] = n_over; red_i[tid >> 6] = intlargest; red_l[tid >> 6] = largest; red_s[tid >> 6] = st; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; w++) {
+            n_over += red_n[w];
+            intlargest = red_i[w] > intlargest ? red_i[w] : intlargest;
+            largest = red_l[w] > largest ? red_l[w] : largest;
+            st |= red_s[w];
+        }
+        of.n_overflows += n_over; of.intlargest = intlargest; of.largest = largest;
+        for (int m = 0; m < job.n_members; m++) over[mem[m].channel] = of;     // bfrun.c:1999-2001
+        if (st) atomicOr(status, st);
+    }
 }
 
 // ------------------------------------------------------------------ K3d: HP-TPDF dithered requantiser

@@ -91,6 +91,17 @@ void bfhip_engine_destroy(bfhip_engine *e);
 
 /* dai_buffer_format[io]->bf[channel] (dai.c:537-576); 1:1 virtual:physical channels */
 int bfhip_engine_set_format(bfhip_engine *e, int io, int channel, const bfhip_format *bf);
+/* N:1 virtual -> physical channel mapping (`mapping:` in an input/output device section,
+   bfconf->virt2phys / n_virtperphys).  The virtual channels of one physical channel must be
+   consecutive.  After this call bfhip_engine_set_format addresses PHYSICAL channels.  For
+   channels that share a physical one, integer delay and mute happen inside the block like in
+   filter_process() (bfrun.c:1509-1531, 1938-2003; delay.c) -- set them with the calls below at
+   any time (what bfaccess->set_delay / toggle_mute write into icomm).  For 1:1 channels delay and
+   mute are dai.c's business on the raw buffers and these settings are ignored. */
+int bfhip_engine_map_channels(bfhip_engine *e, int io, int n_phys, const int virt2phys[]);
+int bfhip_engine_set_delay(bfhip_engine *e, int io, int virt_channel, int delay_samples);
+int bfhip_engine_set_maxdelay(bfhip_engine *e, int io, int virt_channel, int maxdelay);  /* <0: fixed */
+int bfhip_engine_set_mute(bfhip_engine *e, int io, int virt_channel, int muted);
 /* bfconf->safety_limit (linear, 0 = off), bfconf.c "safety_limit" setting */
 int bfhip_engine_set_safety_limit(bfhip_engine *e, double limit);
 /* outputs to dither + dither_init() parameters (dither.c:75-139, bfconf.c:3170-3230) */

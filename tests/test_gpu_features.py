@@ -371,3 +371,55 @@ def test_processed_coefficient_format_round_trip(hip, rs):
     bad[1, 7] = np.nan
     with pytest.raises(hip.BfhipError, match="NaN or Inf"):
         hip.Engine(L, N, rs, 1, 1).add_coeff_processed(bad)
+
+
+@pytest.mark.parametrize("rs", [4, 8])
+def test_virtual_channels_delay_mute_and_mix(hip, rs):
+    """bench4_config's `mapping`: virtual inputs that share a physical input (each with its own
+    integer delay / mute) and virtual outputs mixed into one physical output (bfrun.c:1509-1531,
+    1938-2003; delay.c).  Delays change at run time across the short / long buffer regimes."""
+    L, N = 128, 4
+    coeffs = [(_ir(80 + k, L * N, 2), 1.0, 0) for k in range(4)]
+    filters = [dict(in_ch=[0], out_ch=[0], coeff=0), dict(in_ch=[1], out_ch=[1], coeff=1),
+               dict(in_ch=[2], out_ch=[2], coeff=2), dict(in_ch=[3], out_ch=[3], coeff=3),
+               dict(in_ch=[1, 3], out_ch=[0], coeff=0, in_scale=[0.5, -0.5])]
+    ifmt, ofmt = "S16_LE", FLOATFMT[rs]
+
+    def mk(cls):
+        e = cls(L, N, rs, 4, 4)
+        e.map_channels(0, [0, 0, 0, 1])          # three virtual inputs from physical input 0
+        e.map_channels(1, [0, 1, 1, 2])          # virtual outputs 1,2 mix into physical output 1
+        e.set_interleaved_phys(0, ifmt, 2)
+        e.set_interleaved_phys(1, ofmt, 3)
+        for t, s, nb in coeffs:
+            e.add_coeff(t, s, nb)
+        for v, (d, md) in enumerate([(0, 300), (17, 300), (200, -1), (0, 0)]):
+            e.set_delay(0, v, d); e.set_maxdelay(0, v, md)
+        for v, (d, md) in enumerate([(0, 0), (5, 400), (130, 400), (0, 0)]):
+            e.set_delay(1, v, d); e.set_maxdelay(1, v, md)
+        for f in filters:
+            e.add_filter(**f)
+        if hasattr(e, "finalize"):
+            e.finalize()
+        return e
+    ge, oe = mk(hip.Engine), mk(bo.Engine)
+    plan = {2: [(0, 1, 40)], 3: [(1, 1, 0)], 4: [(0, 0, 129), (1, 2, 7)], 6: [(0, 1, 290)],
+            8: [(0, 0, 3), (1, 1, 399)], 9: [(0, 1, 17)], 11: [(1, 2, 128)]}
+    mutes = {3: [(0, 1, 1)], 5: [(0, 1, 0), (1, 2, 1)], 7: [(1, 2, 0), (1, 1, 1)], 10: [(1, 1, 0)]}
+    blocks = cases.raw_blocks(21, 14, L, 2, ifmt, amplitude=0.2)
+    for b, blk in enumerate(blocks):
+        for eng in (ge, oe):
+            for io, v, d in plan.get(b, []):
+                eng.set_delay(io, v, d)
+            for io, v, m in mutes.get(b, []):
+                eng.set_mute(io, v, m)
+        gs, g = ge.block(blk)
+        os_, o = oe.block(blk)
+        assert gs == os_ == 0
+        gsamp, osamp = cases.samples(g, ofmt), cases.samples(o, ofmt)
+        if np.abs(osamp).max() > 0:
+            assert cases.rel_rms(gsamp, osamp) <= TOL[rs], b
+    for ch in range(4):
+        g, o = ge.overflow(ch), oe.overflow(ch)
+        assert (g.n_overflows, g.max) == (o.n_overflows, o.max)
+        assert g.largest == pytest.approx(o.largest, rel=1e-5)
