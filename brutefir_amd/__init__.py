@@ -83,6 +83,8 @@ def lib():
     L.bfhip_engine_destroy.argtypes = [vp]
     L.bfhip_engine_set_format.argtypes = [vp, ci, ci, C.POINTER(Format)]
     L.bfhip_engine_set_safety_limit.argtypes = [vp, cd]
+    L.bfhip_engine_enable_subdelay.argtypes = [vp, ci, cd]
+    L.bfhip_engine_set_subdelay.argtypes = [vp, ci, ci, ci]
     L.bfhip_engine_map_channels.argtypes = [vp, ci, ci, ip]
     for f in ("bfhip_engine_set_delay", "bfhip_engine_set_maxdelay", "bfhip_engine_set_mute"):
         getattr(L, f).argtypes = [vp, ci, ci, ci]
@@ -204,6 +206,12 @@ class Engine:
 
     def set_mute(self, io, ch, muted):
         _check(lib().bfhip_engine_set_mute(self.h, io, ch, int(muted)))
+
+    def enable_subdelay(self, sdf_length, beta=9.0):
+        _check(lib().bfhip_engine_enable_subdelay(self.h, sdf_length, beta))
+
+    def set_subdelay(self, io, ch, subdelay):
+        _check(lib().bfhip_engine_set_subdelay(self.h, io, ch, subdelay))
 
     def enable_dither(self, channels, sample_rate, max_size=0):
         _check(lib().bfhip_engine_enable_dither(self.h, _iarr(list(channels)), len(channels),

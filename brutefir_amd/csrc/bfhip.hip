@@ -227,6 +227,15 @@ struct bfhip_engine {
     int vjobs_turn = 0;
     bool has_vchan = false;
 
+    // sub-sample delay (sdf_length / sdf_beta / per-channel subdelay; delay.c:416-505)
+    int sdf_length = 0, sd_flen = 0, sd_bs = 0;
+    std::vector<int> subdelay[2];          // current value per virtual channel (-100 = undefined)
+    std::vector<int> sd_slot[2];           // filter slot of a channel, -1 = none (fixed at finalize)
+    void *d_sd_bank = nullptr;             // [199][flen] taps, index 99 + subdelay
+    void *d_sd_rest[2] = {nullptr, nullptr};
+    void *d_sdin = nullptr;                // [n filtered inputs][L] reals, what K1 reads
+    void *d_sdjobs[2] = {nullptr, nullptr};
+
     // HP-TPDF dither (dither.c, dither.h)
     std::vector<int> dither_channels;      // output channel of each dither slot
     std::vector<int8_t> dither_table;
@@ -756,6 +765,13 @@ int upload_formats(bfhip_engine *e) {
                 f.sample_spacing = 1;
                 f.byte_offset = 0;
             }
+            if (io == 0 && e->sd_slot[0][v] >= 0) {
+                // sub-sample filtered: K1 reads the filtered reals (the conversion from the
+                // raw format happened in the filter pass)
+                f.alt = (const uint8_t *)e->d_sdin + (size_t)e->sd_slot[0][v] * e->L * e->rs;
+                f.isfloat = 1; f.swap = 0; f.bytes = e->rs; f.sbytes = e->rs;
+                f.sample_spacing = 1; f.byte_offset = 0;
+            }
             d.push_back(f);
         }
         if (!d.empty()) HIPCHK(hipMemcpy(e->d_fmt[io], d.data(), d.size() * sizeof(DevFormat), hipMemcpyHostToDevice));
@@ -785,6 +801,57 @@ int ensure_ready(bfhip_engine *e) {
     return BFHIP_OK;
 }
 
+bool side_uses_subdelay(const bfhip_engine *e, int io) {
+    if (e->sdf_length <= 0) return false;
+    for (int s : e->sd_slot[io]) if (s >= 0) return true;
+    return false;
+}
+
+// sub-sample delay of the channels that have a filter (bfrun.c:1503-1508 apply_subdelay, :1921-1925)
+template <typename T>
+int do_subdelay_t(bfhip_engine *e, int io, const void *rawin_dev) {
+    std::vector<SdJob<T>> jobs;
+    for (int v = 0; v < e->n_ch[io]; v++) {
+        const int slot = e->sd_slot[io][v];
+        if (slot < 0) continue;
+        SdJob<T> j;
+        memset(&j, 0, sizeof(j));
+        const int sd = e->subdelay[io][v];
+        j.taps = (sd > -100 && sd < 100) ? (const T *)e->d_sd_bank + (size_t)(99 + sd) * e->sd_flen : nullptr;
+        j.rest = (T *)e->d_sd_rest[io] + (size_t)slot * e->sd_bs;
+        if (io == 0) {
+            const bfhip_format &f = e->fmt[0][e->v2p[0][v]];
+            j.fmt = to_dev(f);
+            if (e->n_vpp[0][e->v2p[0][v]] > 1) {              // the delayed private copy
+                size_t k = 0;
+                while (e->vin_list[k] != v) k++;
+                j.raw = e->d_incopy + k * (size_t)e->L * 8;
+                j.fmt.sample_spacing = 1; j.fmt.byte_offset = 0;
+            } else {
+                j.raw = (const uint8_t *)rawin_dev;
+            }
+            j.dst = (T *)e->d_sdin + (size_t)slot * e->L;
+        } else {
+            j.src = (const T *)e->d_timeout + (size_t)v * e->L;
+            j.dst = (T *)e->d_timeout + (size_t)v * e->L;
+        }
+        jobs.push_back(j);
+    }
+    if (jobs.empty()) return BFHIP_OK;
+    HIPCHK(hipMemcpyAsync(e->d_sdjobs[io], jobs.data(), jobs.size() * sizeof(SdJob<T>), hipMemcpyHostToDevice, e->ls));
+    const size_t lds = (size_t)(e->sd_bs + e->L) * sizeof(T);
+    auto k = subdelay_fir_kernel<T>;
+    HIPCHK(allow_lds(k, lds));
+    hipLaunchKernelGGL(k, dim3((unsigned)jobs.size()), dim3(256), lds, e->ls, (const SdJob<T> *)e->d_sdjobs[io], e->L, e->sd_bs, e->sd_flen);
+    HIPCHK(hipGetLastError());
+    return BFHIP_OK;
+}
+
+int do_subdelay(bfhip_engine *e, int io, const void *rawin_dev) {
+    if (e->sdf_length <= 0) return BFHIP_OK;
+    return e->rs == 4 ? do_subdelay_t<float>(e, io, rawin_dev) : do_subdelay_t<double>(e, io, rawin_dev);
+}
+
 // N:1 inputs: gather + mute + integer delay into the private copies K1 reads (bfrun.c:1509-1531)
 int do_vin(bfhip_engine *e, const void *rawin_dev) {
     if (e->vin_list.empty()) return BFHIP_OK;
@@ -798,7 +865,8 @@ int do_vin(bfhip_engine *e, const void *rawin_dev) {
         j.byte_offset = f.byte_offset; j.sample_spacing = f.sample_spacing; j.bytes = f.bytes;
         j.muted = e->vmuted[0][v];
         j.ops_off = (int)ops.size();
-        if (!j.muted) e->vline[0][v].update(j.copy, e->vdelay[0][v], ops);   // not advanced when muted
+        const int extra = (side_uses_subdelay(e, 0) && e->sd_slot[0][v] < 0) ? e->sdf_length : 0;   // bfrun.c:1512-1516
+        if (!j.muted) e->vline[0][v].update(j.copy, e->vdelay[0][v] + extra, ops);   // not advanced when muted
         j.n_ops = (int)ops.size() - j.ops_off;
         jobs.push_back(j);
     }
@@ -827,7 +895,8 @@ int do_vout(bfhip_engine *e, void *rawout_dev) {
             VOutMember m;
             m.channel = v; m.muted = e->vmuted[1][v]; m.ops_off = (int)ops.size();
             uint8_t *row = (uint8_t *)e->d_timeout + (size_t)v * e->L * e->rs;
-            e->vline[1][v].update(row, e->vdelay[1][v], ops);        // always advanced (:1948)
+            const int extra = (side_uses_subdelay(e, 1) && e->sd_slot[1][v] < 0 && e->n_vpp[1][e->v2p[1][v]] > 1) ? e->sdf_length : 0;
+            e->vline[1][v].update(row, e->vdelay[1][v] + extra, ops);        // always advanced (:1948)
             m.n_ops = (int)ops.size() - m.ops_off;
             mem.push_back(m);
         }
@@ -853,6 +922,7 @@ int do_vout(bfhip_engine *e, void *rawout_dev) {
 
 int do_inputs(bfhip_engine *e, const void *rawin_dev) {
     { int rv = do_vin(e, rawin_dev); if (rv != BFHIP_OK) return rv; }
+    { int rv = do_subdelay(e, 0, rawin_dev); if (rv != BFHIP_OK) return rv; }
     hipError_t err = hipSuccess;
     const int slot = (int)(e->blockcounter % (unsigned int)e->R);
     DISPATCH(launch_fft_in, e, (const uint8_t *)rawin_dev, slot, &err);
@@ -885,6 +955,7 @@ int do_outputs(bfhip_engine *e, const void *Zp, size_t chunk_stride, int n_chunk
         return fail(BFHIP_EINVAL, "outputs that share a physical channel cannot be split over several calls");
     DISPATCH(launch_ifft_out, e, Zp, chunk_stride, n_chunks, first, count, (uint8_t *)rawout_dev, &err);
     if (err != hipSuccess) return fail(BFHIP_EHIP, "ifft_out launch: %s", hipGetErrorString(err));
+    { int rv = do_subdelay(e, 1, nullptr); if (rv != BFHIP_OK) return rv; }
     return do_vout(e, rawout_dev);
 }
 
@@ -893,6 +964,82 @@ void advance(bfhip_engine *e) {
     e->blocks_done++;
     for (auto &f : e->filters) f.prevcoeff = f.coeff;    // bfrun.c:1838
     if (e->any_fading) e->plan_dirty = true;             // the fade lasts exactly one block
+}
+
+}  // namespace
+
+namespace {
+
+
+// Kaiser window exactly as the reference applies it to its sub-sample filters
+// (firwindow.c:12-160 via delay.c:56-76; note the window is applied twice when offset != 0)
+double sd_bessel_i0(double x) {
+    double n = 1.0, a = 1.0, sum = 1.0;
+    const double h = x / 2.0;
+    do { a *= h; a /= n; sum += a * a; n += 1.0; } while (a != 0.0 && std::isfinite(sum));
+    return sum;
+}
+
+template <typename T>
+void sd_make_filter(std::vector<T> &f, int half, double offset, double beta) {
+    const int len = 2 * half + 1;
+    f.assign(len, (T)0);
+    if (offset == 0.0) { f[half] = (T)1; return; }            // delay.c:476-483: a unit pulse
+    for (int n = 0; n < len; n++) {
+        const double x = M_PI * ((double)(n - half) - offset);
+        f[n] = (T)(x == 0.0 ? 1.0 : sin(x) / x);
+    }
+    const double inv = 1.0 / sd_bessel_i0(beta);
+    auto kaiser = [&](double x) {
+        if (x < -1.0) x = -1.0;
+        if (x > 1.0) x = 1.0;
+        return sd_bessel_i0(beta * sqrt(1.0 - x * x)) * inv;
+    };
+    int max = half + (int)floor(offset);
+    offset -= floor(offset);
+    if (fabs(offset) < 1e-20) offset = 0.0;
+    double step = 1.0 / ((double)max + offset);
+    if (offset == 0.0) max -= 1;
+    int n = 0;
+    for (; n <= max; n++) { const double y = kaiser(-1.0 + (double)n * step); f[n] *= y; f[n] *= y; }
+    if (offset == 0.0) max += 1;
+    step = 1.0 / ((double)(len - max - 1) - offset);
+    for (; n < len; n++) { const double y = kaiser(((double)(n - max) - offset) * step); f[n] *= y; f[n] *= y; }
+}
+
+int subdelay_setup(bfhip_engine *e) {
+    if (e->sdf_length <= 0) return BFHIP_OK;
+    int n_slots[2] = {0, 0};
+    for (int io = 0; io < 2; io++)
+        for (int v = 0; v < e->n_ch[io]; v++)
+            e->sd_slot[io][v] = e->subdelay[io][v] != -100 ? n_slots[io]++ : -1;      // bfrun.c:1133-1142
+    if (n_slots[0] + n_slots[1] == 0) { e->sdf_length = 0; return BFHIP_OK; }
+    // bank: index 99 + subdelay, subdelay in (-100, 100) hundredths of a sample (BF_SAMPLE_SLOTS)
+    std::vector<unsigned char> bank((size_t)199 * e->sd_flen * e->rs);
+    for (int sd = -99; sd <= 99; sd++) {
+        if (e->rs == 4) {
+            std::vector<float> f;
+            sd_make_filter(f, e->sdf_length, (double)sd / 100, 9.0);
+            memcpy(bank.data() + (size_t)(99 + sd) * e->sd_flen * 4, f.data(), f.size() * 4);
+        } else {
+            std::vector<double> f;
+            sd_make_filter(f, e->sdf_length, (double)sd / 100, 9.0);
+            memcpy(bank.data() + (size_t)(99 + sd) * e->sd_flen * 8, f.data(), f.size() * 8);
+        }
+    }
+    HIPCHK(hipMalloc(&e->d_sd_bank, bank.size()));
+    HIPCHK(hipMemcpy(e->d_sd_bank, bank.data(), bank.size(), hipMemcpyHostToDevice));
+    for (int io = 0; io < 2; io++) {
+        if (n_slots[io] == 0) continue;
+        HIPCHK(hipMalloc(&e->d_sd_rest[io], (size_t)n_slots[io] * e->sd_bs * e->rs));
+        HIPCHK(hipMemset(e->d_sd_rest[io], 0, (size_t)n_slots[io] * e->sd_bs * e->rs));
+        HIPCHK(hipMalloc(&e->d_sdjobs[io], (size_t)n_slots[io] * 128));
+    }
+    if (n_slots[0] > 0) {
+        HIPCHK(hipMalloc(&e->d_sdin, (size_t)n_slots[0] * e->L * e->rs));
+        HIPCHK(hipMemset(e->d_sdin, 0, (size_t)n_slots[0] * e->L * e->rs));
+    }
+    return BFHIP_OK;
 }
 
 }  // namespace
@@ -946,6 +1093,8 @@ bfhip_engine *bfhip_engine_create(int device, int length, int n_blocks, int real
         e->vdelay[io].assign(e->n_ch[io], 0);
         e->vmaxdelay[io].assign(e->n_ch[io], 0);
         e->vmuted[io].assign(e->n_ch[io], 0);
+        e->subdelay[io].assign(e->n_ch[io], -100);       // BF_UNDEFINED_SUBDELAY
+        e->sd_slot[io].assign(e->n_ch[io], -1);
     }
     bool ok = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) == hipSuccess;
     e->own_stream = ok;
@@ -977,6 +1126,8 @@ void bfhip_engine_destroy(bfhip_engine *e) {
     for (void *p : e->promoted) if (p) (void)hipFree(p);
     for (int io = 0; io < 2; io++) for (auto &dl : e->vline[io]) if (dl.arena) (void)hipFree(dl.arena);
     if (e->d_incopy) (void)hipFree(e->d_incopy);
+    { void *sp[] = {e->d_sd_bank, e->d_sd_rest[0], e->d_sd_rest[1], e->d_sdin, e->d_sdjobs[0], e->d_sdjobs[1]};
+      for (void *q : sp) if (q) (void)hipFree(q); }
     if (e->d_vjobs) (void)hipFree(e->d_vjobs);
     if (e->d_Zp2) (void)hipFree(e->d_Zp2);
     for (int i = 0; i < 2; i++) {
@@ -1043,6 +1194,25 @@ int bfhip_engine_set_maxdelay(bfhip_engine *e, int io, int ch, int maxdelay) {
 int bfhip_engine_set_mute(bfhip_engine *e, int io, int ch, int muted) {
     if (!e || io < 0 || io > 1 || ch < 0 || ch >= e->n_ch[io]) return fail(BFHIP_EINVAL, "set_mute: bad argument");
     e->vmuted[io][ch] = muted != 0;
+    return BFHIP_OK;
+}
+
+int bfhip_engine_enable_subdelay(bfhip_engine *e, int sdf_length, double kaiser_beta) {
+    (void)kaiser_beta;       // parsed by the reference (sdf_beta) but its filters are built with 9 (delay.c:73)
+    if (!e) return fail(BFHIP_EINVAL, "null engine");
+    if (e->finalized) return fail(BFHIP_ESTATE, "enable_subdelay after finalize");
+    if (sdf_length < 1) return fail(BFHIP_EINVAL, "Invalid half filter length %d.", sdf_length);
+    if (2 * sdf_length + 1 > e->L) return fail(BFHIP_EINVAL, "The filter_length must be at least 2 x sdf_length + 1.");
+    int bs = 1;
+    while (bs < 2 * sdf_length + 1) bs <<= 1;
+    if (e->L % bs != 0) return fail(BFHIP_EINVAL, "Incompatible fragment/filter sizes (%d/%d).", e->L, 2 * sdf_length + 1);
+    e->sdf_length = sdf_length; e->sd_flen = 2 * sdf_length + 1; e->sd_bs = bs;
+    return BFHIP_OK;
+}
+
+int bfhip_engine_set_subdelay(bfhip_engine *e, int io, int ch, int subdelay) {
+    if (!e || io < 0 || io > 1 || ch < 0 || ch >= e->n_ch[io]) return fail(BFHIP_EINVAL, "set_subdelay: bad argument");
+    e->subdelay[io][ch] = subdelay;
     return BFHIP_OK;
 }
 
@@ -1297,28 +1467,36 @@ int bfhip_engine_finalize(bfhip_engine *e) {
     HIPCHK(hipMemset(e->d_prev, 0, prev_b));       // bfrun.c:1388: everything starts zeroed
     HIPCHK(hipMemset(e->d_ring, 0, ring_b));
     for (int io = 0; io < 2; io++) HIPCHK(hipMalloc((void **)&e->d_fmt[io], e->n_ch[io] * sizeof(DevFormat)));
+    { int rs_ = subdelay_setup(e); if (rs_ != BFHIP_OK) return rs_; }
     // channels that share a physical channel: private copies, delay lines, job tables
     {
         e->vin_list.clear(); e->vout_groups.clear();
         for (int v = 0; v < e->n_ch[0]; v++) if (e->n_vpp[0][e->v2p[0][v]] > 1) e->vin_list.push_back(v);
         for (int v = 0; v < e->n_ch[1]; v++) {
-            if (e->n_vpp[1][e->v2p[1][v]] <= 1) continue;
+            if (e->n_vpp[1][e->v2p[1][v]] <= 1) {
+                // a 1:1 output with a sub-sample filter is requantised after the filter: a group of one
+                if (e->sd_slot[1][v] >= 0) e->vout_groups.push_back({v});
+                continue;
+            }
             if (e->vout_groups.empty() || e->v2p[1][e->vout_groups.back()[0]] != e->v2p[1][v]) e->vout_groups.push_back({});
             e->vout_groups.back().push_back(v);
         }
-        e->has_vchan = !e->vin_list.empty() || !e->vout_groups.empty();
+        e->has_vchan = !e->vin_list.empty() || !e->vout_groups.empty() || e->sdf_length > 0;
         if (e->has_vchan) {
             if (!e->dither_channels.empty()) return fail(BFHIP_EINVAL, "dither on outputs that share a physical channel is not supported");
             size_t n_ops_max = 0;
             e->vline[0].assign(e->n_ch[0], DelayLine());
             e->vline[1].assign(e->n_ch[1], DelayLine());
             for (int v : e->vin_list) {
-                int rr = e->vline[0][v].init(e->L, e->vdelay[0][v], e->vmaxdelay[0][v], e->fmt[0][e->v2p[0][v]].bytes);
+                const int extra = (side_uses_subdelay(e, 0) && e->sd_slot[0][v] < 0) ? e->sdf_length : 0;    // bfrun.c:1152-1162
+                int rr = e->vline[0][v].init(e->L, e->vdelay[0][v] + extra, e->vmaxdelay[0][v] + extra, e->fmt[0][e->v2p[0][v]].bytes);
                 if (rr != BFHIP_OK) return fail(rr, "delay buffer allocation failed");
                 n_ops_max += e->vline[0][v].n_full_cap + 10;
             }
             for (auto &g : e->vout_groups) for (int v : g) {
-                int rr = e->vline[1][v].init(e->L, e->vdelay[1][v], e->vmaxdelay[1][v], e->rs);
+                const int extra = (side_uses_subdelay(e, 1) && e->sd_slot[1][v] < 0 && g.size() > 1) ? e->sdf_length : 0;
+                int rr = g.size() > 1 ? e->vline[1][v].init(e->L, e->vdelay[1][v] + extra, e->vmaxdelay[1][v] + extra, e->rs)
+                                      : e->vline[1][v].init(e->L, 0, 0, e->rs);     // 1:1: dai.c delays it
                 if (rr != BFHIP_OK) return fail(rr, "delay buffer allocation failed");
                 n_ops_max += e->vline[1][v].n_full_cap + 10;
             }
@@ -1328,6 +1506,7 @@ int bfhip_engine_finalize(bfhip_engine *e) {
             }
             e->vjobs_slot = (n_ops_max + 8) * sizeof(ByteOp) + (e->n_ch[0] + e->n_ch[1] + 8) * 64;
             HIPCHK(hipMalloc(&e->d_vjobs, 2 * e->vjobs_slot));
+            e->vline[0].resize(e->n_ch[0]); e->vline[1].resize(e->n_ch[1]);
             if (!e->vout_groups.empty()) {
                 std::vector<unsigned char> skip(e->n_ch[1], 0);
                 for (auto &g : e->vout_groups) for (int v : g) skip[v] = 1;

@@ -1087,6 +1087,49 @@ vchan_out_kernel(const VOutJob *__restrict__ jobs, const VOutMember *__restrict_
     }
 }
 
+// ------------------------------------------------------------------ sub-sample delay
+
+// delay_subsample_update (delay.c:416-442) runs a small FFT overlap-save (convolver_td_*) over
+// the block; what it computes is the causal FIR  y[n] = sum_k h[k] x[n - k]  with h one of 199
+// Kaiser-windowed sinc filters of 2*sdf_length+1 taps and the history carried in a `rest`
+// buffer.  Here it is evaluated directly: one workgroup per channel, block + history in LDS.
+template <typename T> struct SdJob {
+    const uint8_t *raw;     // raw samples (input side, converted on the fly) or null
+    DevFormat fmt;          // of raw
+    const T *src;           // real samples when raw is null (may equal dst)
+    T *dst;                 // [L] filtered block
+    T *rest;                // [bs] last bs unfiltered samples of the previous block
+    const T *taps;          // [flen], null: sub-delay out of range -> block passes unchanged,
+                            // history NOT updated (the reference returns early)
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void
+subdelay_fir_kernel(const SdJob<T> *__restrict__ jobs, int L, int bs, int flen) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T *xx = reinterpret_cast<T *>(smem);          // [bs + L] = [history | block]
+    const SdJob<T> job = jobs[blockIdx.x];
+    const int tid = threadIdx.x;
+    for (int n = tid; n < L; n += 256) {
+        T v;
+        if (job.raw) v = load_raw<T>(job.raw + job.fmt.byte_offset + (size_t)n * job.fmt.sample_spacing * job.fmt.bytes, job.fmt);
+        else v = job.src[n];
+        xx[bs + n] = v;
+    }
+    if (job.taps) for (int n = tid; n < bs; n += 256) xx[n] = job.rest[n];
+    __syncthreads();
+    if (job.taps == nullptr) {
+        for (int n = tid; n < L; n += 256) job.dst[n] = xx[bs + n];
+        return;
+    }
+    for (int n = tid; n < L; n += 256) {
+        T acc = (T)0;
+        for (int k = 0; k < flen; k++) acc += job.taps[k] * xx[bs + n - k];
+        job.dst[n] = acc;
+    }
+    for (int n = tid; n < bs; n += 256) job.rest[n] = xx[L + n];
+}
+
 // ------------------------------------------------------------------ K3d: HP-TPDF dithered requantiser
 
 // dither_funs.h:7-69 + dither.h:28-38.  The error feedback {1,-1} makes sample n depend on

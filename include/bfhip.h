@@ -102,6 +102,15 @@ int bfhip_engine_map_channels(bfhip_engine *e, int io, int n_phys, const int vir
 int bfhip_engine_set_delay(bfhip_engine *e, int io, int virt_channel, int delay_samples);
 int bfhip_engine_set_maxdelay(bfhip_engine *e, int io, int virt_channel, int maxdelay);  /* <0: fixed */
 int bfhip_engine_set_mute(bfhip_engine *e, int io, int virt_channel, int muted);
+/* sub-sample delay: `sdf_length` (half length of the Kaiser-windowed sinc filters; > 0 enables)
+   and per-channel `subdelay:` in hundredths of a sample, range (-100, 100); -100
+   (BF_UNDEFINED_SUBDELAY) = the channel has no filter.  Which channels have one is fixed at
+   finalize; the value may change at run time (bfaccess->set_subdelay).  A filtered channel is
+   delayed by sdf_length + subdelay/100 samples (delay.c:416-505); a channel WITHOUT a filter that
+   shares a physical channel is delayed by sdf_length whole samples (bfrun.c:1152-1162). */
+#define BFHIP_UNDEFINED_SUBDELAY (-100)
+int bfhip_engine_enable_subdelay(bfhip_engine *e, int sdf_length, double kaiser_beta);
+int bfhip_engine_set_subdelay(bfhip_engine *e, int io, int virt_channel, int subdelay);
 /* bfconf->safety_limit (linear, 0 = off), bfconf.c "safety_limit" setting */
 int bfhip_engine_set_safety_limit(bfhip_engine *e, double limit);
 /* outputs to dither + dither_init() parameters (dither.c:75-139, bfconf.c:3170-3230) */

@@ -524,6 +524,121 @@ bfo_firwindow_kaiser(void *target, int len, double offset, double beta, int real
     }
 }
 
+/* ============================ td_conv + sub-sample delay (fftw_convolver.c:682-782, delay.c:416-505) */
+
+typedef struct {
+    bfo_ctx *fc;          /* FFT context of length blocklen (transforms of 2*blocklen reals) */
+    int blocklen;
+    void *coeffs;         /* halfcomplex, scaled by 1/(2*blocklen) */
+} otd;
+
+static int
+td_block_length(int n)
+{
+    int o = 0;
+    if (n < 1) return -1;
+    while ((1 << o) < n) o++;
+    return 1 << o;
+}
+
+static otd *
+td_new(const void *coeffs, int n_coeffs, int rs)
+{
+    otd *t = calloc(1, sizeof(*t));
+    int n;
+    t->blocklen = td_block_length(n_coeffs);
+    t->fc = bfo_ctx_new(t->blocklen < 4 ? 4 : t->blocklen, rs);
+    t->coeffs = calloc(2 * (size_t)t->blocklen, rs);
+    memcpy((uint8_t *)t->coeffs + (size_t)t->blocklen * rs, coeffs, (size_t)n_coeffs * rs);
+    bfo_time2freq(t->fc, t->coeffs, t->coeffs);
+    for (n = 0; n < 2 * t->blocklen; n++) {
+        if (rs == 4) ((float *)t->coeffs)[n] *= 1.0 / (float)(t->blocklen << 1);   /* scalef, :724 */
+        else ((double *)t->coeffs)[n] *= 1.0 / (double)(t->blocklen << 1);
+    }
+    return t;
+}
+
+static void
+td_convolve(const otd *t, void *blk, int rs)
+{
+    const int size = t->blocklen << 1, half = size >> 1;
+    int n;
+    bfo_time2freq(t->fc, blk, blk);
+    if (rs == 4) {                                   /* convolve_inplace_ordered, :738-765 */
+        float *b = blk; const float *c = t->coeffs;
+        b[0] *= c[0];
+        for (n = 1; n < half; n++) {
+            const float a = b[n];
+            b[n] = a * c[n] - b[size - n] * c[size - n];
+            b[size - n] = a * c[size - n] + b[size - n] * c[n];
+        }
+        b[half] *= c[half];
+    } else {
+        double *b = blk; const double *c = t->coeffs;
+        b[0] *= c[0];
+        for (n = 1; n < half; n++) {
+            const double a = b[n];
+            b[n] = a * c[n] - b[size - n] * c[size - n];
+            b[size - n] = a * c[size - n] + b[size - n] * c[n];
+        }
+        b[half] *= c[half];
+    }
+    bfo_freq2time(t->fc, blk, blk);
+}
+
+typedef struct {
+    int steps, flen, fbsize, rs;
+    otd **bank;           /* index -steps+1 .. steps-1 via bank[steps + i] */
+} osubdelay;
+
+static osubdelay *
+subdelay_new(int step_count, int half_len, double beta, int fragment, int rs)
+{
+    osubdelay *sd = calloc(1, sizeof(*sd));
+    void *f;
+    int i, n;
+    (void)beta;                                      /* the reference passes 9, not beta (delay.c:79) */
+    sd->steps = step_count; sd->rs = rs;
+    sd->flen = 2 * half_len + 1;
+    sd->fbsize = td_block_length(sd->flen);
+    if (fragment % sd->fbsize != 0) { free(sd); return NULL; }
+    sd->bank = calloc(2 * step_count + 1, sizeof(otd *));
+    f = calloc(sd->flen, rs);
+    if (rs == 4) ((float *)f)[sd->flen >> 1] = 1.0f; else ((double *)f)[sd->flen >> 1] = 1.0;
+    sd->bank[step_count] = td_new(f, sd->flen, rs);
+    for (i = -step_count + 1; i < step_count; i++) {
+        const double offset = (double)i / step_count;
+        if (i == 0) continue;
+        for (n = 0; n < sd->flen; n++) {             /* sample_sinc, delay.c:56-76 */
+            const double x = M_PI * ((double)(n - half_len) - offset);
+            const double v = x == 0.0 ? 1.0 : sin(x) / x;
+            if (rs == 4) ((float *)f)[n] = (float)v; else ((double *)f)[n] = v;
+        }
+        bfo_firwindow_kaiser(f, sd->flen, offset, 9, rs);
+        sd->bank[step_count + i] = td_new(f, sd->flen, rs);
+    }
+    free(f);
+    return sd;
+}
+
+/* delay_subsample_update, delay.c:416-442 */
+static void
+subdelay_update(const osubdelay *sd, void *buf, void *rest, int subdelay, int fragment)
+{
+    const size_t bs = (size_t)sd->fbsize * sd->rs;
+    uint8_t *cb = malloc(2 * bs);
+    size_t i;
+    if (subdelay <= -sd->steps || subdelay >= sd->steps) { free(cb); return; }
+    for (i = 0; i < (size_t)fragment * sd->rs; i += bs) {
+        memcpy(cb, rest, bs);
+        memcpy(cb + bs, (uint8_t *)buf + i, bs);
+        memcpy(rest, cb + bs, bs);
+        td_convolve(sd->bank[sd->steps + subdelay], cb, sd->rs);
+        memcpy((uint8_t *)buf + i, cb, bs);
+    }
+    free(cb);
+}
+
 /* ============================================================== block level */
 
 typedef struct {
@@ -569,6 +684,11 @@ struct bfo_engine {
     int *delay[2], *maxdelay[2], *muted[2];
     bfo_delay **db[2];              /* input_db / output_db, bfrun.c:1059-1060 */
     void *incopy, *mixbuf;
+    /* sub-sample delay: bfconf->use_subdelay / subdelay[][] / sdf_length */
+    osubdelay *sd;
+    int sdf_length;
+    int *subdelay[2];
+    void **sd_rest[2];
 };
 
 static void *
@@ -604,6 +724,9 @@ bfo_engine_new(int length, int n_blocks, int realsize, int n_in, int n_out)
         e->maxdelay[io] = calloc(e->n_ch[io], sizeof(int));
         e->muted[io] = calloc(e->n_ch[io], sizeof(int));
         e->db[io] = calloc(e->n_ch[io], sizeof(bfo_delay *));
+        e->subdelay[io] = malloc(e->n_ch[io] * sizeof(int));
+        e->sd_rest[io] = calloc(e->n_ch[io], sizeof(void *));
+        { int q; for (q = 0; q < e->n_ch[io]; q++) e->subdelay[io][q] = -100; }   /* BF_UNDEFINED_SUBDELAY */
         for (n = 0; n < e->n_ch[io]; n++) { e->v2p[io][n] = n; e->n_vpp[io][n] = 1; }
     }
     e->incopy = calloc((size_t)length, 8);
@@ -716,6 +839,39 @@ void bfo_engine_set_maxdelay(bfo_engine *e, int io, int ch, int maxdelay) { e->m
 void bfo_engine_set_mute(bfo_engine *e, int io, int ch, int muted) { e->muted[io][ch] = muted; }
 
 int
+bfo_engine_enable_subdelay(bfo_engine *e, int sdf_length, double beta)
+{
+    if (sdf_length <= 0 || 2 * sdf_length + 1 > e->L) return 0;       /* bfconf.c:2796-2805 */
+    e->sd = subdelay_new(100, sdf_length, beta, e->L, e->rs);         /* BF_SAMPLE_SLOTS */
+    e->sdf_length = sdf_length;
+    return e->sd != NULL;
+}
+
+void bfo_engine_set_subdelay(bfo_engine *e, int io, int ch, int subdelay) { e->subdelay[io][ch] = subdelay; }
+
+static int
+side_uses_subdelay(const bfo_engine *e, int io)
+{
+    int n;
+    if (e->sd == NULL) return 0;
+    for (n = 0; n < e->n_ch[io]; n++) if (e->subdelay[io][n] != -100) return 1;
+    return 0;
+}
+
+static void
+apply_subdelay(bfo_engine *e, int io, int ch, void *buf)
+{
+    if (e->sd == NULL || e->subdelay[io][ch] == -100) {
+        if (e->sd_rest[io][ch] == NULL) return;
+    }
+    if (e->sd_rest[io][ch] == NULL) {
+        if (e->sd == NULL || e->subdelay[io][ch] == -100) return;     /* bfrun.c:1133-1142: decided at start */
+        e->sd_rest[io][ch] = calloc(e->sd->fbsize, e->rs);
+    }
+    subdelay_update(e->sd, buf, e->sd_rest[io][ch], e->subdelay[io][ch], e->L);
+}
+
+int
 bfo_engine_add_coeff(bfo_engine *e, const void *taps, int n_taps, double scale, int n_blocks)
 {
     const int L = e->L;
@@ -826,8 +982,13 @@ bfo_engine_block(bfo_engine *e, const void *rawin, void *rawout)
     for (n = 0; n < e->n_ch[0]; n++) {
         const int ph = e->v2p[0][n];
         const bfo_format *bf = &e->fmt[0][ph];
+        const size_t halfb = (size_t)e->L * e->rs;
         if (e->n_vpp[0][ph] == 1) {
-            bfo_raw2cbuf(c, rawin, e->in_time[cur][n], e->in_time[!cur][n], bf);
+            /* convolver_raw2cbuf with the apply_subdelay post-process (bfrun.c:1503-1508) */
+            bfo_raw2real(c, e->in_time[!cur][n], (const uint8_t *)rawin + bf->byte_offset, bf->bytes,
+                         bf->isfloat, bf->sample_spacing, bf->swap, e->L);
+            apply_subdelay(e, 0, n, e->in_time[!cur][n]);
+            memcpy((uint8_t *)e->in_time[cur][n] + halfb, e->in_time[!cur][n], halfb);
         } else {
             /* :1509-1531: several virtual inputs share a physical one: private copy of the raw
                samples, integer delay or mute applied here (dai.c does it for 1:1 channels) */
@@ -837,13 +998,19 @@ bfo_engine_block(bfo_engine *e, const void *rawin, void *rawout)
                 const uint8_t *src = (const uint8_t *)rawin + bf->byte_offset;
                 const size_t st = (size_t)bf->sample_spacing * bf->bytes;
                 for (i = 0; i < e->L; i++) memcpy((uint8_t *)e->incopy + (size_t)i * bf->bytes, src + i * st, bf->bytes);
+                /* channels without a sub-sample filter are delayed by its integer part
+                   (bfrun.c:1152-1162, 1512-1516) */
+                const int extra = (side_uses_subdelay(e, 0) && e->subdelay[0][n] == -100) ? e->sdf_length : 0;
                 if (e->db[0][n] == NULL)
-                    e->db[0][n] = bfo_delay_new(e->L, e->delay[0][n], e->maxdelay[0][n], bf->bytes);
-                bfo_delay_update(e->db[0][n], e->incopy, e->delay[0][n]);
+                    e->db[0][n] = bfo_delay_new(e->L, e->delay[0][n] + extra,
+                                                e->maxdelay[0][n] + extra, bf->bytes);
+                bfo_delay_update(e->db[0][n], e->incopy, e->delay[0][n] + extra);
             } else {
                 memset(e->incopy, 0, (size_t)e->L * bf->bytes);
             }
-            bfo_raw2cbuf(c, e->incopy, e->in_time[cur][n], e->in_time[!cur][n], &cf);
+            bfo_raw2real(c, e->in_time[!cur][n], e->incopy, cf.bytes, cf.isfloat, 1, cf.swap, e->L);
+            apply_subdelay(e, 0, n, e->in_time[!cur][n]);
+            memcpy((uint8_t *)e->in_time[cur][n] + halfb, e->in_time[!cur][n], halfb);
         }
         bfo_time2freq(c, e->in_time[cur][n], e->in_freq[n]);
     }
@@ -944,15 +1111,17 @@ bfo_engine_block(bfo_engine *e, const void *rawin, void *rawout)
                 bfo_mixnscale(c, src, e->out_freq[n], scales, cnt, BFO_MIX_OUTPUT);
             }
             bfo_freq2time(c, e->out_freq[n], e->tmp_out);
+            apply_subdelay(e, 1, n, e->tmp_out);                              /* :1921-1925 */
             if (e->n_vpp[1][ph] == 1) {
                 /* :1926-1936; the probe of sample 0 (:1903-1911) is subsumed by cbuf2raw's test */
                 r = bfo_cbuf2raw(e->c, e->tmp_out, rawout, bf, e->dither_ch[ph], &e->overflow[n],
                                  e->safety_limit);
             } else {
                 /* :1938-2003 */
+                const int extra = (side_uses_subdelay(e, 1) && e->subdelay[1][n] == -100) ? e->sdf_length : 0;
                 if (e->db[1][n] == NULL)
-                    e->db[1][n] = bfo_delay_new(e->L, e->delay[1][n], e->maxdelay[1][n], e->rs);
-                bfo_delay_update(e->db[1][n], e->tmp_out, e->delay[1][n]);
+                    e->db[1][n] = bfo_delay_new(e->L, e->delay[1][n] + extra, e->maxdelay[1][n] + extra, e->rs);
+                bfo_delay_update(e->db[1][n], e->tmp_out, e->delay[1][n] + extra);
                 if (!e->muted[1][n]) {
                     if (!filled) {
                         memcpy(e->mixbuf, e->tmp_out, (size_t)e->L * e->rs);

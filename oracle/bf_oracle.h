@@ -125,6 +125,13 @@ int bfo_engine_map_channels(bfo_engine *e, int io, int n_phys, const int virt2ph
 void bfo_engine_set_delay(bfo_engine *e, int io, int virt_channel, int delay);
 void bfo_engine_set_maxdelay(bfo_engine *e, int io, int virt_channel, int maxdelay);
 void bfo_engine_set_mute(bfo_engine *e, int io, int virt_channel, int muted);
+/* sub-sample delay (`sdf_length`, `sdf_beta`, per-channel `subdelay:`; delay.c:416-505 on
+   top of convolver_td_*).  subdelay in (-100, 100) hundredths of a sample; -100 = channel has
+   no sub-sample filter (BF_UNDEFINED_SUBDELAY) and, if it shares a physical channel, is delayed
+   by sdf_length whole samples instead.  Whether a channel has a filter is fixed at the first
+   block.  Returns 1 / 0. */
+int bfo_engine_enable_subdelay(bfo_engine *e, int sdf_length, double beta);
+void bfo_engine_set_subdelay(bfo_engine *e, int io, int virt_channel, int subdelay);
 /* load_coeff, bfconf.c:1867-2030: split n_taps into n_blocks partitions of L
    (n_blocks <= 0: ceil(n_taps / L), capped to N).  Returns coeff index or -1. */
 int bfo_engine_add_coeff(bfo_engine *e, const void *taps, int n_taps, double scale,

@@ -117,6 +117,8 @@ def lib():
         L.bfo_engine_map_channels.argtypes = [vp, ci, ci, C.POINTER(ci)]
         for f in ("bfo_engine_set_delay", "bfo_engine_set_maxdelay", "bfo_engine_set_mute"):
             getattr(L, f).argtypes = [vp, ci, ci, ci]
+        L.bfo_engine_enable_subdelay.argtypes = [vp, ci, cd]
+        L.bfo_engine_set_subdelay.argtypes = [vp, ci, ci, ci]
         L.bfo_engine_add_coeff.argtypes = [vp, vp, ci, cd, ci]
         ip, dp = C.POINTER(ci), C.POINTER(cd)
         L.bfo_engine_add_filter.argtypes = [vp, ci, ip, dp, ci, ip, dp, ci, ip, dp, ci, ci, ci]
@@ -300,6 +302,13 @@ class Engine:
 
     def set_mute(self, io, ch, muted):
         lib().bfo_engine_set_mute(self.h, io, ch, int(muted))
+
+    def enable_subdelay(self, sdf_length, beta=9.0):
+        if not lib().bfo_engine_enable_subdelay(self.h, sdf_length, beta):
+            raise ValueError("invalid sdf_length")
+
+    def set_subdelay(self, io, ch, subdelay):
+        lib().bfo_engine_set_subdelay(self.h, io, ch, subdelay)
 
     def enable_dither(self, channels, sample_rate, max_size=0):
         return lib().bfo_engine_enable_dither(self.h, _iarr(channels), len(channels),

@@ -423,3 +423,49 @@ def test_virtual_channels_delay_mute_and_mix(hip, rs):
         g, o = ge.overflow(ch), oe.overflow(ch)
         assert (g.n_overflows, g.max) == (o.n_overflows, o.max)
         assert g.largest == pytest.approx(o.largest, rel=1e-5)
+
+
+@pytest.mark.parametrize("rs", [4, 8])
+def test_subsample_delay_inputs_and_outputs(hip, rs):
+    """`sdf_length` + per-channel `subdelay:` (delay.c:416-505): filtered 1:1 inputs and outputs,
+    a filtered member of an N:1 output group, an unfiltered member that gets the integer
+    sdf_length compensation, and a run-time change of the sub-sample value (incl. out of
+    range = filter bypassed for that block).  The reference evaluates the interpolator with a
+    small FFT overlap-save, the device as a direct FIR: same numbers to rounding."""
+    L, N, half = 256, 4, 15
+    coeffs = [(_ir(95 + k, L * N, 1), 1.0, 0) for k in range(3)]
+    filters = [dict(in_ch=[0], out_ch=[0], coeff=0), dict(in_ch=[1], out_ch=[1], coeff=1),
+               dict(in_ch=[2], out_ch=[2], coeff=2), dict(in_ch=[0], out_ch=[2], coeff=-1, in_scale=[0.25])]
+    ofmt = FLOATFMT[rs]
+
+    def mk(cls):
+        e = cls(L, N, rs, 3, 3)
+        e.map_channels(1, [0, 1, 1])             # virtual outputs 1, 2 share physical output 1
+        e.set_interleaved(0, "S24_4LE")
+        e.set_interleaved_phys(1, ofmt, 2)
+        e.enable_subdelay(half)
+        e.set_subdelay(0, 0, 37)                 # input 0 filtered, input 1 and 2 not
+        e.set_subdelay(0, 2, 0)
+        e.set_subdelay(1, 0, -60)                # 1:1 output with a filter
+        e.set_subdelay(1, 1, 12)                 # member of the shared output with a filter
+        for v, d in enumerate([0, 3, 140]):      # output 2 (no filter) gets +sdf_length inside
+            e.set_delay(1, v, d); e.set_maxdelay(1, v, 300)
+        for t, s_, nb in coeffs:
+            e.add_coeff(t, s_, nb)
+        for f in filters:
+            e.add_filter(**f)
+        if hasattr(e, "finalize"):
+            e.finalize()
+        return e
+    ge, oe = mk(hip.Engine), mk(bo.Engine)
+    changes = {3: [(0, 0, -99)], 5: [(1, 0, 150)], 6: [(1, 0, 5)], 8: [(1, 1, -1), (0, 2, 99)]}
+    tol = 2e-5 if rs == 4 else 1e-11             # 31-tap FIR, FFT vs direct summation order
+    for b, blk in enumerate(cases.raw_blocks(33, 12, L, 3, "S24_4LE", amplitude=0.2)):
+        for eng in (ge, oe):
+            for io, v, sd in changes.get(b, []):
+                eng.set_subdelay(io, v, sd)
+        gs, g = ge.block(blk)
+        os_, o = oe.block(blk)
+        assert gs == os_ == 0
+        gsamp, osamp = cases.samples(g, ofmt), cases.samples(o, ofmt)
+        assert cases.rel_rms(gsamp, osamp) <= tol, (b, cases.rel_rms(gsamp, osamp))

@@ -212,3 +212,38 @@ def test_virtual_channel_mapping_delay_and_mute():
     assert np.abs(y[:, 1] - x[:, 1]).max() < 1e-12       # the 1:1 channel is untouched
     # the overflow struct of a physical output is shared by its virtual channels (:1999-2001)
     assert e.overflow(0).astuple() == e.overflow(1).astuple()
+
+
+@pytest.mark.parametrize("rs,tol", [(4, 2e-5), (8, 1e-9)])
+def test_subsample_delay_is_a_fractional_shift(rs, tol):
+    """sub-sample delay (delay.c:416-505): a band-limited signal through a dirac filter with
+    `subdelay: k` on the input comes out delayed by sdf_length + k/100 samples"""
+    L, N, half = 256, 2, 15
+    e = bo.Engine(L, N, rs, 2, 2)
+    e.set_interleaved(0, "FLOAT64_LE")
+    e.set_interleaved(1, "FLOAT64_LE")
+    e.enable_subdelay(half)
+    e.set_subdelay(0, 0, 37)             # input 0: +0.37 samples
+    e.set_subdelay(1, 1, -25)            # output 1: -0.25 samples
+    e.add_filter(in_ch=[0], out_ch=[0], coeff=-1)
+    e.add_filter(in_ch=[1], out_ch=[1], coeff=-1)
+    nblk = 8
+    t = np.arange(nblk * L, dtype=np.float64)
+    f0 = 0.031                                       # cycles / sample: well inside the passband
+    x = np.stack([np.sin(2 * np.pi * f0 * t), np.cos(2 * np.pi * f0 * t)], axis=1)
+    y = np.concatenate([e.block(x[b * L:(b + 1) * L])[1].view(np.float64).reshape(L, 2) for b in range(nblk)])
+    s = slice(3 * L, 7 * L)
+    want0 = np.sin(2 * np.pi * f0 * (t - half - 0.37))
+    want1 = np.cos(2 * np.pi * f0 * (t - half + 0.25))
+    # the windowed-sinc interpolator is not exact: 31 taps with the reference's squared Kaiser(9)
+    assert np.abs(y[s, 0] - want0[s]).max() < 2e-3
+    assert np.abs(y[s, 1] - want1[s]).max() < 2e-3
+    # subdelay 0 is a pure delay of sdf_length samples, exact to rounding
+    e2 = bo.Engine(L, N, rs, 1, 1)
+    e2.set_interleaved(0, "FLOAT64_LE"); e2.set_interleaved(1, "FLOAT64_LE")
+    e2.enable_subdelay(half)
+    e2.set_subdelay(0, 0, 0)
+    e2.add_filter(in_ch=[0], out_ch=[0], coeff=-1)
+    r = np.random.default_rng(1).standard_normal((nblk * L, 1))
+    y2 = np.concatenate([e2.block(r[b * L:(b + 1) * L])[1].view(np.float64) for b in range(nblk)])
+    assert np.abs(y2[half:] - r[:-half, 0]).max() < tol
