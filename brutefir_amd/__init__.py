@@ -119,6 +119,23 @@ def lib():
     L.bfhip_engine_algorithmic_bytes.argtypes = [vp, dp]
     L.bfhip_engine_read_output_spectrum.argtypes = [vp, ci, vp]
     L.bfhip_engine_read_ring_slot.argtypes = [vp, ci, ci, vp]
+    # non-uniform partitioned convolver (include/bfhip_nupc.h)
+    L.bfhip_nupc_last_error.restype = C.c_char_p
+    L.bfhip_nupc_create.restype = vp
+    L.bfhip_nupc_create.argtypes = [ci, ci, ci, ci, ci, ip, ip]
+    L.bfhip_nupc_destroy.argtypes = [vp]
+    L.bfhip_nupc_taps.restype = C.c_long
+    L.bfhip_nupc_taps.argtypes = [vp]
+    L.bfhip_nupc_latency.argtypes = [vp]
+    L.bfhip_nupc_set_format.argtypes = [vp, ci, ci, C.POINTER(Format)]
+    L.bfhip_nupc_set_safety_limit.argtypes = [vp, cd]
+    L.bfhip_nupc_add_filter.argtypes = [vp, ci, ci, vp, C.c_long, cd, cd]
+    L.bfhip_nupc_finalize.argtypes = [vp]
+    L.bfhip_nupc_block.argtypes = [vp, vp, vp, C.POINTER(Overflow)]
+    L.bfhip_nupc_block_dev.argtypes = [vp, vp, vp]
+    L.bfhip_nupc_sync.argtypes = [vp]
+    L.bfhip_nupc_get_overflow.argtypes = [vp, ci, C.POINTER(Overflow)]
+    L.bfhip_engine_set_overlap.argtypes = [vp, ci]
     _lib = L
     return L
 
@@ -342,6 +359,65 @@ class Engine:
         z = np.empty(self.L, self.cdt)
         _check(lib().bfhip_engine_read_ring_slot(self.h, ch, slot, _ptr(z)))
         return z
+
+
+class Nupc:
+    """Non-uniform partitioned convolver (bfhip_nupc): low-latency first block."""
+
+    def __init__(self, seg_length, seg_blocks, realsize, n_in, n_out, device=0):
+        self.rs, self.n_in, self.n_out = realsize, n_in, n_out
+        self.dt = np.float32 if realsize == 4 else np.float64
+        self.h = lib().bfhip_nupc_create(device, realsize, n_in, n_out, len(seg_length),
+                                         _iarr(list(seg_length)), _iarr(list(seg_blocks)))
+        if not self.h:
+            raise BfhipError(lib().bfhip_nupc_last_error().decode())
+        self.L0 = lib().bfhip_nupc_latency(self.h)
+        self.taps = lib().bfhip_nupc_taps(self.h)
+        self.out_bytes = n_out * self.L0 * realsize
+
+    def _chk(self, r):
+        if r < 0:
+            raise BfhipError("bfhip nupc error %d: %s" % (r, lib().bfhip_nupc_last_error().decode()))
+        return r
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().bfhip_nupc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def set_interleaved(self, io, name):
+        n = self.n_in if io == IN else self.n_out
+        for c, f in enumerate(interleaved_formats(name, n)):
+            self._chk(lib().bfhip_nupc_set_format(self.h, io, c, C.byref(f)))
+        if io == OUT:
+            self.out_bytes = n * self.L0 * SAMPLE_FORMATS[name][0]
+
+    def add_filter(self, in_ch, out_ch, taps, in_scale=1.0, out_scale=1.0):
+        taps = np.ascontiguousarray(taps, self.dt)
+        self._chk(lib().bfhip_nupc_add_filter(self.h, in_ch, out_ch, _ptr(taps), len(taps), in_scale, out_scale))
+
+    def finalize(self):
+        self._chk(lib().bfhip_nupc_finalize(self.h))
+
+    def block(self, rawin):
+        rawin = np.ascontiguousarray(rawin).view(np.uint8).ravel()
+        out = np.zeros(self.out_bytes, np.uint8)
+        st = self._chk(lib().bfhip_nupc_block(self.h, _ptr(rawin), _ptr(out), None))
+        return st, out
+
+    def block_dev(self, rawin_dev, rawout_dev):
+        self._chk(lib().bfhip_nupc_block_dev(self.h, _ptr(rawin_dev), _ptr(rawout_dev)))
+
+    def sync(self):
+        return self._chk(lib().bfhip_nupc_sync(self.h))
+
+    def overflow(self, ch):
+        of = Overflow()
+        self._chk(lib().bfhip_nupc_get_overflow(self.h, ch, C.byref(of)))
+        return of
 
 
 def device_count():

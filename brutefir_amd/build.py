@@ -10,8 +10,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbfhip.so")
-SOURCES = ["bfhip.hip", "convolver_abi.hip"]
-DEPS = ["bfhip.hip", "convolver_abi.hip", "kernels.h", "fft_lds.h",
+SOURCES = ["bfhip.hip", "convolver_abi.hip", "nupc.hip"]
+DEPS = ["bfhip.hip", "convolver_abi.hip", "nupc.hip", "kernels.h", "fft_lds.h",
+        os.path.join("..", "..", "include", "bfhip_nupc.h"),
         os.path.join("..", "..", "include", "bfhip.h"),
         os.path.join("..", "..", "include", "bfhip_convolver.h")]
 

@@ -173,6 +173,7 @@ struct bfhip_engine {
     // block t, the way the reference overlaps its input, filter and output processes
     // (bfrun.c:2312-2616).  Needs one spare ring slot (R = N + 1) and two Zp buffers.
     bool pipelined = false;            // decided at finalize (or BFHIP_OVERLAP=0/1)
+    int overlap_mode = -1;             // -1 auto, 0 off, 1 on (bfhip_engine_set_overlap)
     hipStream_t s_in = nullptr, s_out = nullptr;
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_mac[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
     int R = 0;                         // depth of the input rings
@@ -1155,6 +1156,13 @@ int bfhip_engine_set_format(bfhip_engine *e, int io, int ch, const bfhip_format 
     return BFHIP_OK;
 }
 
+int bfhip_engine_set_overlap(bfhip_engine *e, int mode) {
+    if (!e) return fail(BFHIP_EINVAL, "null engine");
+    if (e->finalized) return fail(BFHIP_ESTATE, "set_overlap after finalize");
+    e->overlap_mode = mode;
+    return BFHIP_OK;
+}
+
 int bfhip_engine_set_safety_limit(bfhip_engine *e, double limit) {
     if (!e) return fail(BFHIP_EINVAL, "null engine");
     e->safety_limit = limit;
@@ -1457,6 +1465,7 @@ int bfhip_engine_finalize(bfhip_engine *e) {
             bytes += (double)cblocks_of(e, f.coeff, d) * e->L * e->csize() * std::max<size_t>(1, f.out_ch.size());
         }
         e->pipelined = bytes / 6.4e12 < 100e-6;
+        if (e->overlap_mode >= 0) e->pipelined = e->overlap_mode != 0;
         if (const char *env = getenv("BFHIP_OVERLAP")) e->pipelined = atoi(env) != 0;
         for (int io = 0; io < 2; io++) for (int c : e->n_vpp[io]) if (c > 1) e->pipelined = false;   // one job table per side
     }

@@ -1,0 +1,395 @@
+// nupc.hip -- non-uniform partitioned convolution (low-latency first block) on top of the
+// uniform engines.  An EXTENSION: the reference only has uniform partitions
+// (`filter_length: L,N`, bfconf.c:1495-1520); BASELINE.json's room-correction
+// config asks for "non-uniform partition sizes (low-latency first block)".  Results are the
+// same linear convolution a uniform run computes (tests compare against the oracle's uniform
+// engine on the same stream); only the I/O block -- the latency -- shrinks from L to the
+// smallest segment length.
+//
+// The impulse response is cut into segments; segment k is a uniform partitioned convolver
+// (a bfhip_engine) with partition length L_k (ascending powers of two) and N_k partitions,
+// covering taps [off_k, off_k + N_k * L_k), off_0 = 0.  I/O happens in blocks of L_0 frames.
+// After input block b, every segment whose block is complete ((b+1) * L_0 multiple of L_k)
+// runs on the last L_k frames; its L_k output frames belong at absolute sample
+// (b+1) * L_0 - L_k + off_k and are added into a time-domain accumulator ring; then the L_0
+// frames of output block b are requantised out of the ring.  A contribution is in time iff
+//     off_k >= L_k - L_0
+// (checked at create); e.g. 2 x 64, 2 x 128, ... doubling satisfies it with equality + L_0.
+// All segments of a step are computed at the step (no spreading over earlier steps: this is a
+// throughput/latency engine, the real-time scheduling of the long segments is the host's).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/bfhip_nupc.h"
+#include "kernels.h"
+
+using namespace bfhip;
+
+namespace {
+
+// acc[(pos + j) mod A][o] += seg[j][o] for an L_k x n_out block of a segment's output
+template <typename T>
+__global__ __launch_bounds__(256) void
+nupc_accumulate_kernel(T *__restrict__ acc, const T *__restrict__ seg, unsigned long long pos,
+                       int A, int n_out, int n_frames) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n_frames * n_out) return;
+    const size_t j = i / n_out, o = i % n_out;
+    acc[(size_t)((pos + j) % (unsigned long long)A) * n_out + o] += seg[i];
+}
+
+// output block b: L_0 frames out of the ring, scaled into output units, requantised like
+// convolver_cbuf2raw (real2raw.h / dither_funs.h:71-114), ring region cleared.  One workgroup
+// per output channel.
+template <typename T>
+__global__ __launch_bounds__(256) void
+nupc_emit_kernel(T *__restrict__ acc, unsigned long long pos, int A, int n_out, int L0,
+                 const DevFormat *__restrict__ fmt, const double *__restrict__ inv_scale,
+                 DevOverflow *__restrict__ over, uint8_t *__restrict__ raw, double safety_limit,
+                 int *__restrict__ status) {
+    __shared__ unsigned int red_n[4];
+    __shared__ int32_t red_i[4];
+    __shared__ double red_l[4];
+    __shared__ int red_s[4];
+    const int ch = blockIdx.x, tid = threadIdx.x;
+    const DevFormat f = fmt[ch];
+    DevOverflow of = over[ch];
+    uint8_t *base = raw + f.byte_offset;
+    const size_t stride = (size_t)f.sample_spacing * f.bytes;
+    const int bits = f.sbytes << 3;
+    const int32_t imin = (int32_t)(-((uint64_t)1 << (bits - 1)));
+    const int32_t imax = (int32_t)(((uint64_t)1 << (bits - 1)) - 1);
+    const double rmin_i = (double)(T)imin, rmax_i = (double)(T)imax;
+    const T rmin_f = (T)(-of.max), rmax_f = (T)of.max;
+    const T sc = (T)inv_scale[ch];
+    unsigned int n_over = 0;
+    int32_t intlargest = of.intlargest;
+    double largest = of.largest;
+    int st = 0;
+    for (int n = tid; n < L0; n += 256) {
+        T *cell = &acc[(size_t)((pos + n) % (unsigned long long)A) * n_out + ch];
+        const T x = *cell * sc;
+        *cell = (T)0;
+        uint8_t tb[8];
+        if (!isfinite(x)) { st |= 1; continue; }
+        if (safety_limit != 0.0 && ((double)x < -safety_limit * of.max || (double)x > safety_limit * of.max)) { st |= 2; continue; }
+        if (f.isfloat) {
+            if (x < (T)0) {
+                if (x < rmin_f) n_over++;
+                if ((double)x < -largest) largest = -(double)x;
+            } else {
+                if (x > rmax_f) n_over++;
+                if ((double)x > largest) largest = (double)x;
+            }
+            if (f.bytes == 4) {
+                const uint32_t u = __float_as_uint((float)x);
+                tb[0] = u & 0xff; tb[1] = (u >> 8) & 0xff; tb[2] = (u >> 16) & 0xff; tb[3] = u >> 24;
+            } else {
+                const uint64_t u = (uint64_t)__double_as_longlong((double)x);
+                for (int i = 0; i < 8; i++) tb[i] = (u >> (8 * i)) & 0xff;
+            }
+        } else {
+            const uint32_t u = (uint32_t)real2int_no_dither((double)x, rmin_i, rmax_i, imin, imax, n_over, intlargest, largest);
+            tb[0] = u & 0xff; tb[1] = (u >> 8) & 0xff; tb[2] = (u >> 16) & 0xff; tb[3] = u >> 24;
+        }
+        store_raw_bytes(base + (size_t)n * stride, tb, f.bytes, f.swap);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        n_over += __shfl_down(n_over, off);
+        const int32_t oi = __shfl_down(intlargest, off);
+        intlargest = oi > intlargest ? oi : intlargest;
+        const double ol = __shfl_down(largest, off);
+        largest = ol > largest ? ol : largest;
+        st |= __shfl_down(st, off);
+    }
+    if ((tid & 63) == 0) { red_n[tid >> 6] = n_over; red_i[tid >> 6] = intlargest; red_l[tid >> 6] = largest; red_s[tid >> 6] = st; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; w++) {
+            n_over += red_n[w];
+            intlargest = red_i[w] > intlargest ? red_i[w] : intlargest;
+            largest = red_l[w] > largest ? red_l[w] : largest;
+            st |= red_s[w];
+        }
+        over[ch].n_overflows = of.n_overflows + n_over;
+        over[ch].intlargest = intlargest;
+        over[ch].largest = largest;
+        if (st) atomicOr(status, st);
+    }
+}
+
+thread_local std::string n_err;
+
+int nfail(int code, const std::string &msg) { n_err = msg; return code; }
+
+#define NCHK(expr)                                                                          \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) return nfail(BFHIP_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+#define ECHK(expr)                                                                          \
+    do {                                                                                    \
+        int _r = (expr);                                                                    \
+        if (_r < 0) return nfail(_r, std::string(#expr) + ": " + bfhip_last_error());       \
+    } while (0)
+
+struct Seg {
+    int L = 0, N = 0;
+    long off = 0;               // first tap this segment covers
+    bfhip_engine *eng = nullptr;
+    void *d_out = nullptr;      // [L][n_out] reals
+};
+
+}  // namespace
+
+struct bfhip_nupc {
+    int device = 0, rs = 4, n_in = 0, n_out = 0;
+    std::vector<Seg> seg;
+    std::vector<bfhip_format> fmt[2];
+    double safety_limit = 0;
+    bool finalized = false;
+    unsigned long long block = 0;          // L0-blocks processed
+    hipStream_t stream = nullptr;
+    int A = 0;                             // accumulator ring length in frames
+    void *d_acc = nullptr;                 // [A][n_out] reals
+    uint8_t *d_in = nullptr;               // raw input ring: Lmax frames
+    size_t frame_bytes[2] = {0, 0};        // interleaved raw frame size in / out
+    uint8_t *d_rawout = nullptr;
+    DevFormat *d_fmt_out = nullptr;
+    double *d_inv_scale = nullptr;
+    DevOverflow *d_over = nullptr;
+    int *d_status = nullptr;
+};
+
+extern "C" {
+
+const char *bfhip_nupc_last_error(void) { return n_err.c_str(); }
+
+bfhip_nupc *bfhip_nupc_create(int device, int realsize, int n_in, int n_out, int n_segments,
+                              const int seg_length[], const int seg_blocks[]) {
+    if (n_segments < 1 || !seg_length || !seg_blocks || n_in < 1 || n_out < 1) { nfail(BFHIP_EINVAL, "nupc_create: bad argument"); return nullptr; }
+    bfhip_nupc *n = new bfhip_nupc();
+    n->device = device; n->rs = realsize; n->n_in = n_in; n->n_out = n_out;
+    long off = 0;
+    for (int k = 0; k < n_segments; k++) {
+        Seg s;
+        s.L = seg_length[k]; s.N = seg_blocks[k]; s.off = off;
+        if (s.N < 1 || (k > 0 && (s.L <= seg_length[k - 1] || s.L % seg_length[k - 1] != 0))) {
+            nfail(BFHIP_EINVAL, "nupc_create: segment lengths must ascend and divide each other");
+            delete n; return nullptr;
+        }
+        if (off < (long)s.L - seg_length[0]) {
+            char buf[200];
+            snprintf(buf, sizeof(buf), "nupc_create: segment %d (length %d) starts at tap %ld, before %d: its output "
+                     "would not be ready in time", k, s.L, off, s.L - seg_length[0]);
+            nfail(BFHIP_EINVAL, buf);
+            delete n; return nullptr;
+        }
+        off += (long)s.L * s.N;
+        n->seg.push_back(s);
+    }
+    for (auto &s : n->seg) {
+        s.eng = bfhip_engine_create(device, s.L, s.N, realsize, n_in, n_out);
+        if (!s.eng) { nfail(BFHIP_EINVAL, std::string("nupc_create: ") + bfhip_last_error()); bfhip_nupc_destroy(n); return nullptr; }
+    }
+    for (int io = 0; io < 2; io++) {
+        const int c = io ? n_out : n_in;
+        n->fmt[io].resize(c);
+        for (int ch = 0; ch < c; ch++) {
+            bfhip_format &f = n->fmt[io][ch];
+            f.isfloat = 1; f.swap = 0; f.bytes = f.sbytes = realsize; f.scale = 1.0;
+            f.sample_spacing = c; f.byte_offset = ch * realsize;         // interleaved frames
+        }
+    }
+    return n;
+}
+
+void bfhip_nupc_destroy(bfhip_nupc *n) {
+    if (!n) return;
+    (void)hipSetDevice(n->device);
+    if (n->stream) (void)hipStreamSynchronize(n->stream);
+    for (auto &s : n->seg) { if (s.eng) bfhip_engine_destroy(s.eng); if (s.d_out) (void)hipFree(s.d_out); }
+    void *p[] = {n->d_acc, n->d_in, n->d_rawout, n->d_fmt_out, n->d_inv_scale, n->d_over, n->d_status};
+    for (void *q : p) if (q) (void)hipFree(q);
+    if (n->stream) (void)hipStreamDestroy(n->stream);
+    delete n;
+}
+
+long bfhip_nupc_taps(const bfhip_nupc *n) { return n ? n->seg.back().off + (long)n->seg.back().L * n->seg.back().N : 0; }
+int bfhip_nupc_latency(const bfhip_nupc *n) { return n ? n->seg[0].L : 0; }
+
+// raw formats of the L0-frame I/O buffers; frames must be interleaved (every channel of a side
+// has the same sample_spacing = frame size in samples), the way dai.c lays out an interleaved
+// device, because segment k reads L_k consecutive frames of the input ring
+int bfhip_nupc_set_format(bfhip_nupc *n, int io, int ch, const bfhip_format *f) {
+    if (!n || !f || io < 0 || io > 1 || ch < 0 || ch >= (io ? n->n_out : n->n_in)) return nfail(BFHIP_EINVAL, "nupc_set_format: bad argument");
+    if (n->finalized) return nfail(BFHIP_ESTATE, "nupc_set_format after finalize");
+    n->fmt[io][ch] = *f;
+    return BFHIP_OK;
+}
+
+int bfhip_nupc_set_safety_limit(bfhip_nupc *n, double limit) { if (!n) return BFHIP_EINVAL; n->safety_limit = limit; return BFHIP_OK; }
+
+// one filter = one impulse response from an input to an output (taps in host memory, realsize
+// wide); it is cut along the segment boundaries and loaded into every segment's engine
+int bfhip_nupc_add_filter(bfhip_nupc *n, int in_ch, int out_ch, const void *taps, long n_taps,
+                          double in_scale, double out_scale) {
+    if (!n || !taps || n_taps < 1 || in_ch < 0 || in_ch >= n->n_in || out_ch < 0 || out_ch >= n->n_out) return nfail(BFHIP_EINVAL, "nupc_add_filter: bad argument");
+    if (n->finalized) return nfail(BFHIP_ESTATE, "nupc_add_filter after finalize");
+    for (auto &s : n->seg) {
+        const long avail = n_taps - s.off;
+        const long cap = (long)s.L * s.N;
+        const long take = avail < 0 ? 0 : (avail > cap ? cap : avail);
+        std::vector<unsigned char> zero;
+        const void *src = (const unsigned char *)taps + (size_t)s.off * n->rs;
+        if (take == 0) { zero.assign((size_t)n->rs, 0); src = zero.data(); }
+        const int c = bfhip_engine_add_coeff(s.eng, src, take == 0 ? 1 : (int)take, 1.0, take == 0 ? 1 : 0);
+        if (c < 0) return nfail(c, std::string("nupc_add_filter: ") + bfhip_last_error());
+        // the engines emit plain reals: the output format's 1/scale is applied at the emit step
+        const int r = bfhip_engine_add_filter(s.eng, 1, &in_ch, &in_scale, 0, nullptr, nullptr, 1, &out_ch, &out_scale, c, 0, 0);
+        if (r < 0) return nfail(r, std::string("nupc_add_filter: ") + bfhip_last_error());
+    }
+    return BFHIP_OK;
+}
+
+int bfhip_nupc_finalize(bfhip_nupc *n) {
+    if (!n) return nfail(BFHIP_EINVAL, "null");
+    if (n->finalized) return BFHIP_OK;
+    NCHK(hipSetDevice(n->device));
+    NCHK(hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking));
+    for (int io = 0; io < 2; io++) {
+        const int c = io ? n->n_out : n->n_in;
+        const int spacing = n->fmt[io][0].sample_spacing, bytes = n->fmt[io][0].bytes;
+        for (int ch = 0; ch < c; ch++)
+            if (n->fmt[io][ch].sample_spacing != spacing || n->fmt[io][ch].bytes != bytes)
+                return nfail(BFHIP_EINVAL, "nupc: all channels of a side must share one interleaved frame layout");
+        n->frame_bytes[io] = (size_t)spacing * bytes;
+    }
+    const int L0 = n->seg[0].L, Lmax = n->seg.back().L;
+    long reach = 0;
+    for (auto &s : n->seg) reach = std::max(reach, s.off + 2L * s.L);
+    int A = 1;
+    while (A < reach + L0) A <<= 1;
+    n->A = A;
+    NCHK(hipMalloc(&n->d_acc, (size_t)A * n->n_out * n->rs));
+    NCHK(hipMemset(n->d_acc, 0, (size_t)A * n->n_out * n->rs));
+    NCHK(hipMalloc((void **)&n->d_in, (size_t)Lmax * n->frame_bytes[0]));
+    NCHK(hipMemset(n->d_in, 0, (size_t)Lmax * n->frame_bytes[0]));
+    NCHK(hipMalloc((void **)&n->d_rawout, (size_t)L0 * n->frame_bytes[1]));
+    NCHK(hipMemset(n->d_rawout, 0, (size_t)L0 * n->frame_bytes[1]));
+    std::vector<DevFormat> df(n->n_out);
+    std::vector<double> inv(n->n_out);
+    std::vector<DevOverflow> ov(n->n_out);
+    for (int ch = 0; ch < n->n_out; ch++) {
+        const bfhip_format &f = n->fmt[1][ch];
+        df[ch].isfloat = f.isfloat; df[ch].swap = f.swap; df[ch].bytes = f.bytes; df[ch].sbytes = f.sbytes;
+        df[ch].sample_spacing = f.sample_spacing; df[ch].byte_offset = f.byte_offset; df[ch].alt = nullptr;
+        inv[ch] = 1.0 / f.scale;                                         // bfrun.c:1850
+        memset(&ov[ch], 0, sizeof(DevOverflow));
+        ov[ch].max = f.isfloat ? 1.0 : (double)((uint64_t)1 << ((f.sbytes << 3) - 1)) - 1;
+    }
+    NCHK(hipMalloc((void **)&n->d_fmt_out, df.size() * sizeof(DevFormat)));
+    NCHK(hipMemcpy(n->d_fmt_out, df.data(), df.size() * sizeof(DevFormat), hipMemcpyHostToDevice));
+    NCHK(hipMalloc((void **)&n->d_inv_scale, inv.size() * sizeof(double)));
+    NCHK(hipMemcpy(n->d_inv_scale, inv.data(), inv.size() * sizeof(double), hipMemcpyHostToDevice));
+    NCHK(hipMalloc((void **)&n->d_over, ov.size() * sizeof(DevOverflow)));
+    NCHK(hipMemcpy(n->d_over, ov.data(), ov.size() * sizeof(DevOverflow), hipMemcpyHostToDevice));
+    NCHK(hipMalloc((void **)&n->d_status, sizeof(int)));
+    NCHK(hipMemset(n->d_status, 0, sizeof(int)));
+    for (auto &s : n->seg) {
+        for (int ch = 0; ch < n->n_in; ch++) ECHK(bfhip_engine_set_format(s.eng, BFHIP_IN, ch, &n->fmt[0][ch]));
+        for (int ch = 0; ch < n->n_out; ch++) {
+            bfhip_format f;
+            f.isfloat = 1; f.swap = 0; f.bytes = f.sbytes = n->rs; f.scale = 1.0;
+            f.sample_spacing = n->n_out; f.byte_offset = ch * n->rs;
+            ECHK(bfhip_engine_set_format(s.eng, BFHIP_OUT, ch, &f));
+        }
+        ECHK(bfhip_engine_set_overlap(s.eng, 0));          // the segments are ordered on ONE stream
+        ECHK(bfhip_engine_finalize(s.eng));
+        ECHK(bfhip_engine_set_stream(s.eng, n->stream));
+        NCHK(hipMalloc(&s.d_out, (size_t)s.L * n->n_out * n->rs));
+    }
+    n->finalized = true;
+    return BFHIP_OK;
+}
+
+// one I/O block of L_0 frames, device-resident raw buffers, asynchronous on the nupc's stream
+int bfhip_nupc_block_dev(bfhip_nupc *n, const void *rawin_dev, void *rawout_dev) {
+    if (!n || !n->finalized) return nfail(BFHIP_ESTATE, "nupc not finalized");
+    NCHK(hipSetDevice(n->device));
+    const int L0 = n->seg[0].L, Lmax = n->seg.back().L;
+    const unsigned long long end = (n->block + 1) * (unsigned long long)L0;       // samples received
+    // append to the input ring (linear inside one Lmax period: segment blocks are aligned)
+    const size_t wpos = (size_t)((end - L0) % (unsigned long long)Lmax);
+    if ((const uint8_t *)rawin_dev != n->d_in + wpos * n->frame_bytes[0])     // block() uploads straight into the slot
+        NCHK(hipMemcpyAsync(n->d_in + wpos * n->frame_bytes[0], rawin_dev, (size_t)L0 * n->frame_bytes[0], hipMemcpyDeviceToDevice, n->stream));
+    for (auto &s : n->seg) {
+        if (end % (unsigned long long)s.L != 0) continue;
+        const size_t rpos = (size_t)((end - s.L) % (unsigned long long)Lmax);
+        ECHK(bfhip_engine_block_dev(s.eng, n->d_in + rpos * n->frame_bytes[0], s.d_out));
+        const size_t cnt = (size_t)s.L * n->n_out;
+        const unsigned long long pos = end - s.L + (unsigned long long)s.off;
+        if (n->rs == 4)
+            hipLaunchKernelGGL(nupc_accumulate_kernel<float>, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, n->stream,
+                               (float *)n->d_acc, (const float *)s.d_out, pos, n->A, n->n_out, s.L);
+        else
+            hipLaunchKernelGGL(nupc_accumulate_kernel<double>, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, n->stream,
+                               (double *)n->d_acc, (const double *)s.d_out, pos, n->A, n->n_out, s.L);
+        NCHK(hipGetLastError());
+    }
+    const unsigned long long opos = end - L0;
+    if (n->rs == 4)
+        hipLaunchKernelGGL(nupc_emit_kernel<float>, dim3(n->n_out), dim3(256), 0, n->stream, (float *)n->d_acc, opos, n->A, n->n_out, L0,
+                           n->d_fmt_out, n->d_inv_scale, n->d_over, (uint8_t *)rawout_dev, n->safety_limit, n->d_status);
+    else
+        hipLaunchKernelGGL(nupc_emit_kernel<double>, dim3(n->n_out), dim3(256), 0, n->stream, (double *)n->d_acc, opos, n->A, n->n_out, L0,
+                           n->d_fmt_out, n->d_inv_scale, n->d_over, (uint8_t *)rawout_dev, n->safety_limit, n->d_status);
+    NCHK(hipGetLastError());
+    n->block++;
+    return BFHIP_OK;
+}
+
+int bfhip_nupc_sync(bfhip_nupc *n) {
+    if (!n || !n->finalized) return nfail(BFHIP_ESTATE, "nupc not finalized");
+    NCHK(hipSetDevice(n->device));
+    NCHK(hipStreamSynchronize(n->stream));
+    int st = 0;
+    for (auto &s : n->seg) { const int r = bfhip_engine_sync(s.eng); if (r < 0) return nfail(r, bfhip_last_error()); st |= r; }
+    int own = 0;
+    NCHK(hipMemcpy(&own, n->d_status, sizeof(int), hipMemcpyDeviceToHost));
+    if (own) NCHK(hipMemset(n->d_status, 0, sizeof(int)));
+    return st | own;
+}
+
+// host buffers: copies in, runs, copies out, waits; returns status bits
+int bfhip_nupc_block(bfhip_nupc *n, const void *rawin, void *rawout, bfhip_overflow overflow[]) {
+    if (!n || !n->finalized || !rawin || !rawout) return nfail(BFHIP_ESTATE, "nupc_block: bad state or argument");
+    NCHK(hipSetDevice(n->device));
+    const int L0 = n->seg[0].L;
+    // upload straight into this block's slot of the input ring
+    const unsigned long long end = (n->block + 1) * (unsigned long long)L0;
+    const size_t wpos = (size_t)((end - L0) % (unsigned long long)n->seg.back().L);
+    uint8_t *slot = n->d_in + wpos * n->frame_bytes[0];
+    NCHK(hipMemcpyAsync(slot, rawin, (size_t)L0 * n->frame_bytes[0], hipMemcpyHostToDevice, n->stream));
+    if (overflow) NCHK(hipMemcpyAsync(n->d_over, overflow, n->n_out * sizeof(DevOverflow), hipMemcpyHostToDevice, n->stream));
+    int r = bfhip_nupc_block_dev(n, slot, n->d_rawout);
+    if (r < 0) return r;
+    NCHK(hipMemcpyAsync(rawout, n->d_rawout, (size_t)L0 * n->frame_bytes[1], hipMemcpyDeviceToHost, n->stream));
+    if (overflow) NCHK(hipMemcpyAsync(overflow, n->d_over, n->n_out * sizeof(DevOverflow), hipMemcpyDeviceToHost, n->stream));
+    return bfhip_nupc_sync(n);
+}
+
+int bfhip_nupc_get_overflow(bfhip_nupc *n, int ch, bfhip_overflow *of) {
+    if (!n || !n->finalized || !of || ch < 0 || ch >= n->n_out) return nfail(BFHIP_EINVAL, "nupc_get_overflow: bad argument");
+    NCHK(hipSetDevice(n->device));
+    NCHK(hipStreamSynchronize(n->stream));
+    NCHK(hipMemcpy(of, n->d_over + ch, sizeof(DevOverflow), hipMemcpyDeviceToHost));
+    return BFHIP_OK;
+}
+
+}  // extern "C"

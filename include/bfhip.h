@@ -193,6 +193,9 @@ int bfhip_engine_outputs_inputs_dev(bfhip_engine *e, const void *z_dev, int firs
 /* advance blockcounter / curbuf (bfrun.c:2031-2034); block/block_dev do it themselves */
 int bfhip_engine_advance(bfhip_engine *e);
 
+/* before finalize: -1 = decide from the plan (default), 0 = the three kernels of a block on one
+   stream, 1 = on three engine-owned streams (see bfhip_engine_block_dev) */
+int bfhip_engine_set_overlap(bfhip_engine *e, int mode);
 /* hipStream_t to run on (default: a stream owned by the engine) */
 int bfhip_engine_set_stream(bfhip_engine *e, void *hip_stream);
 
