@@ -15,6 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libbfhip.so")
 
 IN, OUT = 0, 1
+RT_SPIN, RT_NO_GRAPH = 1, 2      # bfhip_engine_rt_begin flags
 ST_NONFINITE, ST_SAFETY = 1, 2
 
 
@@ -119,6 +120,15 @@ def lib():
     L.bfhip_engine_algorithmic_bytes.argtypes = [vp, dp]
     L.bfhip_engine_read_output_spectrum.argtypes = [vp, ci, vp]
     L.bfhip_engine_read_ring_slot.argtypes = [vp, ci, ci, vp]
+    ull = C.POINTER(C.c_ulonglong)
+    L.bfhip_engine_rt_begin.argtypes = [vp, ci]
+    L.bfhip_engine_rt_end.argtypes = [vp]
+    L.bfhip_engine_rt_buffer.restype = vp
+    L.bfhip_engine_rt_buffer.argtypes = [vp, ci, ci]
+    L.bfhip_engine_rt_submit.argtypes = [vp, vp]
+    L.bfhip_engine_rt_wait.argtypes = [vp, vp, C.POINTER(Overflow)]
+    L.bfhip_engine_rt_block.argtypes = [vp, vp, vp, C.POINTER(Overflow)]
+    L.bfhip_engine_rt_stats.argtypes = [vp, ull, ull, ull]
     # non-uniform partitioned convolver (include/bfhip_nupc.h)
     L.bfhip_nupc_last_error.restype = C.c_char_p
     L.bfhip_nupc_create.restype = vp
@@ -296,6 +306,32 @@ class Engine:
 
     def block_dev(self, rawin_dev, rawout_dev):
         _check(lib().bfhip_engine_block_dev(self.h, _ptr(rawin_dev), _ptr(rawout_dev)))
+
+    # real-time mode (callback I/O): pinned double buffer + graph replay
+    def rt_begin(self, flags=0):
+        _check(lib().bfhip_engine_rt_begin(self.h, flags))
+
+    def rt_end(self):
+        _check(lib().bfhip_engine_rt_end(self.h))
+
+    def rt_submit(self, rawin):
+        rawin = np.ascontiguousarray(rawin).view(np.uint8).ravel()
+        assert rawin.size >= self.in_bytes, (rawin.size, self.in_bytes)
+        _check(lib().bfhip_engine_rt_submit(self.h, _ptr(rawin)))
+
+    def rt_wait(self, overflow=None):
+        out = np.zeros(self.out_bytes, np.uint8)
+        st = _check(lib().bfhip_engine_rt_wait(self.h, _ptr(out), overflow))
+        return st, out
+
+    def rt_block(self, rawin, overflow=None):
+        self.rt_submit(rawin)
+        return self.rt_wait(overflow)
+
+    def rt_stats(self):
+        a, b, c = C.c_ulonglong(), C.c_ulonglong(), C.c_ulonglong()
+        _check(lib().bfhip_engine_rt_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"graph": a.value, "direct": b.value, "captures": c.value}
 
     def sync(self):
         return _check(lib().bfhip_engine_sync(self.h))

@@ -254,6 +254,27 @@ struct bfhip_engine {
     bool mac_nt = true;            // non-temporal coefficient loads (BFHIP_MAC_NT=0 turns them off)
     double alg_bytes_total = 0, alg_bytes_mac = 0;
 
+    // real-time mode (bfhip_engine_rt_*): pinned host double buffer, the block's launch
+    // sequence replayed from a HIP graph, completion signalled through pinned memory
+    struct Rt {
+        bool on = false;
+        int flags = 0;
+        void *h_in[2] = {nullptr, nullptr}, *h_out[2] = {nullptr, nullptr};
+        DevOverflow *h_over[2] = {nullptr, nullptr};
+        int *h_status[2] = {nullptr, nullptr};      // [0] status bits, [1] sequence number
+        hipGraphExec_t exec[2] = {nullptr, nullptr};
+        bool valid[2] = {false, false};
+        bool primed = false;                        // one direct block ran since the last plan change
+        hipEvent_t done[2] = {nullptr, nullptr};
+        unsigned long long submitted = 0, waited = 0;
+        unsigned int bs_t = 0;                      // what d_bs->t holds
+        bool bs_synced = false;
+        unsigned long long n_graph = 0, n_direct = 0, n_capture = 0;
+    } rt;
+    BlockState *d_bs = nullptr;
+    unsigned int *d_rt_arrive = nullptr;
+    BlockState *bs_arg = nullptr;      // non-null while a graph is being captured
+
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev;    // 6 per block: start/stop of K1, K2, K3 on their streams
@@ -305,7 +326,8 @@ void launch_fft_in(bfhip_engine *e, const uint8_t *raw, int slot, hipError_t *er
     *err = allow_lds(k, lds);
     if (*err != hipSuccess) return;
     hipLaunchKernelGGL(k, dim3(e->n_ch[0]), dim3(NT), lds, e->ls, raw, e->d_fmt[0],
-                       (T *)e->d_prev, (c2<T> *)e->d_ring, (const c2<T> *)e->d_tw, e->R, slot);
+                       (T *)e->d_prev, (c2<T> *)e->d_ring, (const c2<T> *)e->d_tw, e->R, slot,
+                       (const BlockState *)e->bs_arg);
     *err = hipGetLastError();
 }
 
@@ -378,12 +400,12 @@ void launch_mac(bfhip_engine *e, void *Zp, hipError_t *err) {
         hipLaunchKernelGGL((mac_xbar_kernel<T, true>), dim3(grid), dim3(e->mac_threads), 0, e->ls,
                            (const MacEntry<T> *)e->d_entries, (const ChunkRange *)e->d_chunks,
                            (c2<T> *)Zp, e->L, e->n_out_padded, e->n_groups, e->n_chunks, n_tc,
-                           e->blockcounter, (int)age64);
+                           e->blockcounter, (int)age64, (const BlockState *)e->bs_arg);
     else
         hipLaunchKernelGGL((mac_xbar_kernel<T, false>), dim3(grid), dim3(e->mac_threads), 0, e->ls,
                            (const MacEntry<T> *)e->d_entries, (const ChunkRange *)e->d_chunks,
                            (c2<T> *)Zp, e->L, e->n_out_padded, e->n_groups, e->n_chunks, n_tc,
-                           e->blockcounter, (int)age64);
+                           e->blockcounter, (int)age64, (const BlockState *)e->bs_arg);
     *err = hipGetLastError();
 }
 
@@ -414,11 +436,12 @@ void launch_levels(bfhip_engine *e, hipError_t *err) {
             hipLaunchKernelGGL(kf, dim3(lj.n_fill), dim3(NT), lds, e->ls,
                                (const FillJob<T> *)(base + lj.fill_off),
                                (const MixSrc<T> *)(base + e->src_off), (const c2<T> *)e->d_tw,
-                               e->N, e->blockcounter);
+                               e->N, e->blockcounter, (const BlockState *)e->bs_arg);
         }
         if (lj.n_filt > 0) {
             hipLaunchKernelGGL(mac_filter_kernel<T>, dim3(tiles, lj.n_filt), dim3(threads), 0, e->ls,
-                               (const FilterJob<T> *)(base + lj.filt_off), e->L, e->blockcounter, (int)age64);
+                               (const FilterJob<T> *)(base + lj.filt_off), e->L, e->blockcounter, (int)age64,
+                               (const BlockState *)e->bs_arg);
         }
         if (lj.n_fade > 0) {
             if ((*err = allow_lds(kx, lds)) != hipSuccess) return;
@@ -798,7 +821,11 @@ int record(bfhip_engine *e, int idx) {
 int ensure_ready(bfhip_engine *e) {
     if (!e->finalized) return fail(BFHIP_ESTATE, "engine not finalized");
     HIPCHK(hipSetDevice(e->device));
-    if (e->plan_dirty) return build_plan(e);
+    if (e->plan_dirty) {
+        e->rt.valid[0] = e->rt.valid[1] = false;     // captured launches point into the old plan
+        e->rt.primed = false;
+        return build_plan(e);
+    }
     return BFHIP_OK;
 }
 
@@ -967,6 +994,80 @@ void advance(bfhip_engine *e) {
     if (e->any_fading) e->plan_dirty = true;             // the fade lasts exactly one block
 }
 
+// ---------------------------------------------------------------- real-time mode
+
+void rt_release(bfhip_engine *e) {
+    auto &rt = e->rt;
+    for (int p = 0; p < 2; p++) {
+        if (rt.exec[p]) (void)hipGraphExecDestroy(rt.exec[p]);
+        if (rt.done[p]) (void)hipEventDestroy(rt.done[p]);
+        if (rt.h_in[p]) (void)hipHostFree(rt.h_in[p]);
+        if (rt.h_out[p]) (void)hipHostFree(rt.h_out[p]);
+        if (rt.h_over[p]) (void)hipHostFree(rt.h_over[p]);
+        if (rt.h_status[p]) (void)hipHostFree(rt.h_status[p]);
+    }
+    if (e->d_bs) (void)hipFree(e->d_bs);
+    if (e->d_rt_arrive) (void)hipFree(e->d_rt_arrive);
+    e->d_bs = nullptr;
+    e->d_rt_arrive = nullptr;
+    rt = bfhip_engine::Rt();
+}
+
+// can this plan's launch sequence be replayed unchanged block after block?
+bool rt_graphable(const bfhip_engine *e) {
+    if (e->rt.flags & BFHIP_RT_NO_GRAPH) return false;
+    // N:1 channels and sub-sample delays upload a per-block job table; a cross-fade lasts one block
+    return !e->has_vchan && !side_uses_subdelay(e, 0) && !side_uses_subdelay(e, 1) && !e->any_fading;
+}
+
+// the launch sequence of one block on the main stream: pinned in -> device -> pinned out
+int rt_enqueue(bfhip_engine *e, int p) {
+    auto &rt = e->rt;
+    int r;
+    e->ls = e->stream;
+    const bool nodes = (rt.flags & BFHIP_RT_COPY_ENGINE) != 0;
+    RtCopy cin, cout;
+    cin.dst = (uint4 *)e->d_rawin; cin.src = (const uint4 *)rt.h_in[p];
+    cin.n16 = (unsigned int)((e->raw_bytes[0] + 15) / 16); cin.pad = 0;
+    cout.dst = (uint4 *)rt.h_out[p]; cout.src = (const uint4 *)e->d_rawout;
+    cout.n16 = nodes ? 0u : (unsigned int)((e->raw_bytes[1] + 15) / 16); cout.pad = 0;
+    if (nodes) {
+        HIPCHK(hipMemcpyAsync(e->d_rawin, rt.h_in[p], e->raw_bytes[0], hipMemcpyHostToDevice, e->stream));
+    } else {
+        hipLaunchKernelGGL(rt_copy_in_kernel<0>, dim3((cin.n16 + 255) / 256), dim3(256), 0, e->stream, cin);
+        HIPCHK(hipGetLastError());
+    }
+    if ((r = do_inputs(e, e->d_rawin)) != BFHIP_OK) return r;
+    if ((r = do_levels(e)) != BFHIP_OK) return r;
+    if ((r = do_mac(e, e->d_Zp)) != BFHIP_OK) return r;
+    if ((r = do_outputs(e, e->d_Zp, (size_t)e->n_out_padded * e->L, e->n_chunks, 0, e->n_ch[1], e->d_rawout)) != BFHIP_OK) return r;
+    if (nodes) HIPCHK(hipMemcpyAsync(rt.h_out[p], e->d_rawout, e->raw_bytes[1], hipMemcpyDeviceToHost, e->stream));
+    hipLaunchKernelGGL(rt_tail_kernel<0>, dim3(nodes ? 1u : (cout.n16 + 255) / 256), dim3(256), 0, e->stream, cout,
+                       e->d_bs, e->N, (const DevOverflow *)e->d_over, rt.h_over[p], e->n_ch[1], e->d_status,
+                       rt.h_status[p], e->d_rt_arrive);
+    HIPCHK(hipGetLastError());
+    return BFHIP_OK;
+}
+
+int rt_capture(bfhip_engine *e, int p) {
+    auto &rt = e->rt;
+    if (rt.exec[p]) { (void)hipGraphExecDestroy(rt.exec[p]); rt.exec[p] = nullptr; }
+    HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeRelaxed));
+    e->bs_arg = e->d_bs;
+    const int r = rt_enqueue(e, p);
+    e->bs_arg = nullptr;
+    hipGraph_t g = nullptr;
+    const hipError_t ce = hipStreamEndCapture(e->stream, &g);
+    if (r != BFHIP_OK) { if (g) (void)hipGraphDestroy(g); return r; }
+    if (ce != hipSuccess) return fail(BFHIP_EHIP, "graph capture: %s", hipGetErrorString(ce));
+    const hipError_t ie = hipGraphInstantiate(&rt.exec[p], g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (ie != hipSuccess) { rt.exec[p] = nullptr; return fail(BFHIP_EHIP, "graph instantiate: %s", hipGetErrorString(ie)); }
+    rt.valid[p] = true;
+    rt.n_capture++;
+    return BFHIP_OK;
+}
+
 }  // namespace
 
 namespace {
@@ -1129,6 +1230,7 @@ void bfhip_engine_destroy(bfhip_engine *e) {
     if (e->d_incopy) (void)hipFree(e->d_incopy);
     { void *sp[] = {e->d_sd_bank, e->d_sd_rest[0], e->d_sd_rest[1], e->d_sdin, e->d_sdjobs[0], e->d_sdjobs[1]};
       for (void *q : sp) if (q) (void)hipFree(q); }
+    rt_release(e);
     if (e->d_vjobs) (void)hipFree(e->d_vjobs);
     if (e->d_Zp2) (void)hipFree(e->d_Zp2);
     for (int i = 0; i < 2; i++) {
@@ -1533,8 +1635,8 @@ int bfhip_engine_finalize(bfhip_engine *e) {
     HIPCHK(hipMemset(e->d_status, 0, sizeof(int)));
     e->raw_bytes[0] = raw_extent(e->fmt[0], e->n_phys[0], e->L);
     e->raw_bytes[1] = raw_extent(e->fmt[1], e->n_phys[1], e->L);
-    HIPCHK(hipMalloc((void **)&e->d_rawin, e->raw_bytes[0]));
-    HIPCHK(hipMalloc((void **)&e->d_rawout, e->raw_bytes[1]));
+    HIPCHK(hipMalloc((void **)&e->d_rawin, e->raw_bytes[0] + 16));       // +16: staged in 16-byte words
+    HIPCHK(hipMalloc((void **)&e->d_rawout, e->raw_bytes[1] + 16));
     HIPCHK(hipMemset(e->d_rawout, 0, e->raw_bytes[1]));
     // classify filters: who owns a private ring, who must materialise its output
     {
@@ -1773,6 +1875,122 @@ int bfhip_engine_block(bfhip_engine *e, const void *rawin, void *rawout, bfhip_o
     HIPCHK(hipMemcpyAsync(rawout, e->d_rawout, e->raw_bytes[1], hipMemcpyDeviceToHost, sout));
     if (overflow) HIPCHK(hipMemcpyAsync(overflow, e->d_over, e->n_ch[1] * sizeof(DevOverflow), hipMemcpyDeviceToHost, sout));
     return bfhip_engine_sync(e);
+}
+
+int bfhip_engine_rt_begin(bfhip_engine *e, int flags) {
+    int r = ensure_ready(e);
+    if (r != BFHIP_OK) return r;
+    if (e->rt.on) return fail(BFHIP_ESTATE, "rt_begin: already in real-time mode");
+    if ((r = sync_all(e)) != BFHIP_OK) return r;
+    e->pipelined = false;                      // one stream: a period is needed back as soon as possible
+    auto &rt = e->rt;
+    rt.flags = flags;
+    for (int p = 0; p < 2; p++) {
+        HIPCHK(hipHostMalloc(&rt.h_in[p], e->raw_bytes[0] + 16, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(&rt.h_out[p], e->raw_bytes[1] + 16, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&rt.h_over[p], e->n_ch[1] * sizeof(DevOverflow), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&rt.h_status[p], 2 * sizeof(int), hipHostMallocDefault));
+        memset(rt.h_in[p], 0, e->raw_bytes[0]);
+        memset(rt.h_out[p], 0, e->raw_bytes[1]);
+        memset(rt.h_over[p], 0, e->n_ch[1] * sizeof(DevOverflow));
+        rt.h_status[p][0] = rt.h_status[p][1] = 0;
+        HIPCHK(hipEventCreateWithFlags(&rt.done[p], hipEventDisableTiming));
+    }
+    HIPCHK(hipMalloc((void **)&e->d_bs, sizeof(BlockState)));
+    HIPCHK(hipMalloc((void **)&e->d_rt_arrive, sizeof(unsigned int)));
+    HIPCHK(hipMemset(e->d_rt_arrive, 0, sizeof(unsigned int)));
+    rt.on = true;
+    rt.bs_synced = false;
+    return BFHIP_OK;
+}
+
+int bfhip_engine_rt_end(bfhip_engine *e) {
+    if (!e) return fail(BFHIP_EINVAL, "null engine");
+    if (!e->rt.on) return BFHIP_OK;
+    HIPCHK(hipSetDevice(e->device));
+    { int r = sync_all(e); if (r != BFHIP_OK) return r; }
+    rt_release(e);
+    return BFHIP_OK;
+}
+
+void *bfhip_engine_rt_buffer(bfhip_engine *e, int io, int index) {
+    if (!e || !e->rt.on || io < 0 || io > 1 || index < 0 || index > 1) return nullptr;
+    return io == 0 ? e->rt.h_in[index] : e->rt.h_out[index];
+}
+
+int bfhip_engine_rt_submit(bfhip_engine *e, const void *rawin) {
+    if (!e || !e->rt.on) return fail(BFHIP_ESTATE, "rt_submit: not in real-time mode");
+    auto &rt = e->rt;
+    if (rt.submitted - rt.waited >= 2) return fail(BFHIP_ESTATE, "rt_submit: two periods already in flight");
+    int r = ensure_ready(e);                   // control changes since the last block rebuild the plan
+    if (r != BFHIP_OK) return r;
+    const int p = (int)(rt.submitted & 1);
+    if (rawin && rawin != rt.h_in[p]) memcpy(rt.h_in[p], rawin, e->raw_bytes[0]);
+    if (!rt.bs_synced || rt.bs_t != e->blockcounter) {
+        // blocks went through the other entry points (or this is the first period)
+        BlockState bs;
+        bs.t = e->blockcounter;
+        bs.age = (int)std::min<unsigned long long>(e->blocks_done + 1, (unsigned long long)e->N);
+        bs.n_blocks = 0; bs.pad = 0;
+        HIPCHK(hipMemcpyAsync(e->d_bs, &bs, sizeof(bs), hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        rt.bs_synced = true;
+    }
+    rt.h_status[p][1] = 0;
+    if (rt_graphable(e) && rt.primed) {
+        if (!rt.valid[p] && (r = rt_capture(e, p)) != BFHIP_OK) return r;
+        HIPCHK(hipGraphLaunch(rt.exec[p], e->stream));
+        rt.n_graph++;
+    } else {
+        // first block after a plan change (also sets the kernels' LDS attributes outside any
+        // capture), cross-fade blocks, per-block job tables: plain launches
+        if ((r = rt_enqueue(e, p)) != BFHIP_OK) return r;
+        rt.primed = true;
+        rt.n_direct++;
+    }
+    HIPCHK(hipEventRecord(rt.done[p], e->stream));
+    rt.submitted++;
+    advance(e);
+    rt.bs_t = e->blockcounter;
+    return BFHIP_OK;
+}
+
+int bfhip_engine_rt_wait(bfhip_engine *e, void *rawout, bfhip_overflow overflow[]) {
+    if (!e || !e->rt.on) return fail(BFHIP_ESTATE, "rt_wait: not in real-time mode");
+    auto &rt = e->rt;
+    if (rt.submitted == rt.waited) return fail(BFHIP_ESTATE, "rt_wait: nothing in flight");
+    const int p = (int)(rt.waited & 1);
+    HIPCHK(hipSetDevice(e->device));
+    if (rt.flags & BFHIP_RT_SPIN) {
+        // the tail kernel's last store is the sequence word: watch it from the CPU, fall back to
+        // the runtime after ~2 ms so that a device error cannot hang the caller
+        volatile int *seq = rt.h_status[p] + 1;
+        long spin = 0;
+        for (; spin < 2000000 && *seq == 0; spin++) __builtin_ia32_pause();
+        // seen: every store of the block (the tail kernel's copy-out included) is visible
+        if (*seq == 0 || (rt.flags & BFHIP_RT_COPY_ENGINE)) HIPCHK(hipEventSynchronize(rt.done[p]));
+    } else {
+        HIPCHK(hipEventSynchronize(rt.done[p]));
+    }
+    rt.waited++;
+    if (rawout && rawout != rt.h_out[p]) memcpy(rawout, rt.h_out[p], e->raw_bytes[1]);
+    if (overflow) memcpy(overflow, rt.h_over[p], e->n_ch[1] * sizeof(DevOverflow));
+    return rt.h_status[p][0];
+}
+
+int bfhip_engine_rt_block(bfhip_engine *e, const void *rawin, void *rawout, bfhip_overflow overflow[]) {
+    int r = bfhip_engine_rt_submit(e, rawin);
+    if (r != BFHIP_OK) return r;
+    return bfhip_engine_rt_wait(e, rawout, overflow);
+}
+
+int bfhip_engine_rt_stats(const bfhip_engine *e, unsigned long long *graph_blocks,
+                          unsigned long long *direct_blocks, unsigned long long *captures) {
+    if (!e) return fail(BFHIP_EINVAL, "null engine");
+    if (graph_blocks) *graph_blocks = e->rt.n_graph;
+    if (direct_blocks) *direct_blocks = e->rt.n_direct;
+    if (captures) *captures = e->rt.n_capture;
+    return BFHIP_OK;
 }
 
 int bfhip_engine_set_stream(bfhip_engine *e, void *hip_stream) {

@@ -59,6 +59,12 @@ template <typename T> struct MacEntry {
 
 struct ChunkRange { int begin, end; };
 
+// Per-block counters in device memory, for launch sequences replayed from a HIP graph (their
+// kernel arguments are frozen at capture time): t = blockcounter (bfrun.c:2034), age =
+// min(blocks processed + 1, N) (the procblocks guard, bfrun.c:1745).  Kernels take an optional
+// pointer to it; null = use the by-value arguments.  rt_tail_kernel advances it.
+struct BlockState { unsigned int t; int age; int n_blocks; int pad; };
+
 // ------------------------------------------------------------------ raw sample access
 
 template <typename T>
@@ -218,8 +224,10 @@ fft_in_body(int ch, unsigned char *smem, const uint8_t *__restrict__ raw, const 
 template <typename T, int LOG2L>
 __global__ __launch_bounds__(fft_threads<T>(LOG2L)) void
 fft_in_kernel(const uint8_t *__restrict__ raw, const DevFormat *__restrict__ fmt, T *__restrict__ prev,
-              c2<T> *__restrict__ ring, const c2<T> *__restrict__ tw, int R, int slot) {
+              c2<T> *__restrict__ ring, const c2<T> *__restrict__ tw, int R, int slot,
+              const BlockState *__restrict__ bs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (bs) slot = (int)(bs->t % (unsigned int)R);
     fft_in_body<T, LOG2L>(blockIdx.x, smem, raw, fmt, prev, ring, tw, R, slot);
 }
 
@@ -328,8 +336,9 @@ template <typename T, bool NT>
 __global__ __launch_bounds__(256) void
 mac_xbar_kernel(const MacEntry<T> *__restrict__ entries, const ChunkRange *__restrict__ chunks,
                 c2<T> *__restrict__ Zp, int L, int n_out_padded, int n_groups, int n_chunks,
-                int n_tc, unsigned int t, int age) {
+                int n_tc, unsigned int t, int age, const BlockState *__restrict__ bs) {
     constexpr int V = 16 / sizeof(c2<T>);          // bins per lane: 2 (f32) / 1 (f64)
+    if (bs) { t = bs->t; age = bs->age; }
     // XCD-aware decode (blocks b and b+8 share an XCD)
     const int bid = blockIdx.x;
     const int xcd = bid & 7, local = bid >> 3;
@@ -495,12 +504,13 @@ template <typename T> struct MixSrc {
 template <typename T, int LOG2L>
 __global__ __launch_bounds__(fft_threads<T>(LOG2L)) void
 ring_fill_kernel(const FillJob<T> *__restrict__ jobs, const MixSrc<T> *__restrict__ src,
-                 const c2<T> *__restrict__ tw, int N, unsigned int t) {
+                 const c2<T> *__restrict__ tw, int N, unsigned int t, const BlockState *__restrict__ bs) {
     constexpr int L = 1 << LOG2L, NT = fft_threads<T>(LOG2L);
     constexpr int QP = UT<T, LOG2L>::QP, QU = UT<T, LOG2L>::QU;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     LdsArr<T> s{reinterpret_cast<c2<T> *>(smem)};
     const int tid = threadIdx.x;
+    if (bs) t = bs->t;
     const FillJob<T> job = jobs[blockIdx.x];
     c2<T> *dst = job.ring + (size_t)((t + (unsigned int)job.delay) % (unsigned int)N) * L;
     const MixSrc<T> *in = src + job.in_off;
@@ -620,8 +630,10 @@ template <typename T> struct FilterJob {
 
 template <typename T>
 __global__ __launch_bounds__(256) void
-mac_filter_kernel(const FilterJob<T> *__restrict__ jobs, int L, unsigned int t, int age) {
+mac_filter_kernel(const FilterJob<T> *__restrict__ jobs, int L, unsigned int t, int age,
+                  const BlockState *__restrict__ bs) {
     constexpr int V = 16 / sizeof(c2<T>);
+    if (bs) { t = bs->t; age = bs->age; }
     const FilterJob<T> job = jobs[blockIdx.y];
     const int k0 = ((int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x) * V;
     if (k0 >= L) return;
@@ -1219,6 +1231,56 @@ dither_kernel(const T *__restrict__ samples,          // [n_out][L] from ifft_ou
         state[slot] = st;
         over[ch] = of;
         if (flags) atomicOr(status, flags);
+    }
+}
+
+// ------------------------------------------------------------------ real-time tail
+
+// Host <-> device staging of a period as kernels (16 bytes per lane, whole PCIe bursts) rather
+// than copy-engine nodes: inside a replayed graph a kernel node costs less than a memcpy node,
+// and the last one doubles as the block's tail.
+struct RtCopy {
+    uint4 *dst;
+    const uint4 *src;
+    unsigned int n16;        // 16-byte words (buffers are padded to a multiple of 16 bytes)
+    unsigned int pad;
+};
+
+template <int UNUSED>
+__global__ __launch_bounds__(256) void rt_copy_in_kernel(RtCopy c) {
+    const unsigned int i = blockIdx.x * 256u + threadIdx.x;
+    if (i < c.n16) c.dst[i] = c.src[i];
+}
+
+// Last node of a replayed block: copy the raw output to pinned host memory, publish the
+// overflow structs and the status word there too (so the host needs no further copy after the
+// sync) and advance the per-block counters.  The completion word is written by the last
+// workgroup to finish, after a system-scope fence.
+template <int UNUSED>
+__global__ __launch_bounds__(256) void
+rt_tail_kernel(RtCopy c, BlockState *__restrict__ bs, int N, const DevOverflow *__restrict__ over,
+               DevOverflow *__restrict__ host_over, int n_out, int *__restrict__ status,
+               int *__restrict__ host_status, unsigned int *__restrict__ arrive) {
+    const unsigned int i = blockIdx.x * 256u + threadIdx.x;
+    if (i < c.n16) c.dst[i] = c.src[i];
+    if (blockIdx.x == 0) {
+        for (int ch = threadIdx.x; ch < n_out; ch += 256) host_over[ch] = over[ch];
+        if (threadIdx.x == 0) {
+            host_status[0] = *status;
+            *status = 0;
+            bs->t = bs->t + 1u;                              // bfrun.c:2034, unsigned wrap
+            bs->age = bs->age < N ? bs->age + 1 : N;
+            bs->n_blocks = bs->n_blocks + 1;
+        }
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int done = atomicAdd(arrive, 1u) + 1u;
+        if (done == gridDim.x) {
+            *arrive = 0;
+            __hip_atomic_store(host_status + 1, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // "period done"
+        }
     }
 }
 

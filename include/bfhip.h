@@ -193,6 +193,37 @@ int bfhip_engine_outputs_inputs_dev(bfhip_engine *e, const void *z_dev, int firs
 /* advance blockcounter / curbuf (bfrun.c:2031-2034); block/block_dev do it themselves */
 int bfhip_engine_advance(bfhip_engine *e);
 
+/* ---- real-time mode: callback I/O -------------------------------------------------------
+ * The reference's callback I/O (bfio_jack.c:132-200 -> dai.c:111 process_callback ->
+ * bf_callback_ready, bfrun.c:2086-2131) hands filter_process() one period in a shared-memory
+ * buffer and blocks until the filtered period is back; what counts there is the round trip of
+ * ONE block, not throughput.  In this mode the engine owns a pinned host double buffer, keeps
+ * the whole launch sequence of a block (upload, K1, per-filter kernels, K2, K3, dither,
+ * download) in a HIP graph that is replayed with one call, carries the block counter in device
+ * memory and signals completion through pinned memory.  Control changes (set_coeff, set_scale,
+ * ...) keep working: the plan is rebuilt and the next period but one is replayed from a fresh
+ * graph; periods that cannot be replayed (the one-block cross-fade, N:1 channels, sub-sample
+ * delays) are launched normally.  Results are bit-identical to bfhip_engine_block(). */
+#define BFHIP_RT_SPIN     1   /* wait by watching the pinned completion word (lowest latency, burns the core) */
+#define BFHIP_RT_NO_GRAPH 2   /* never replay: plain launches from the pinned buffers */
+#define BFHIP_RT_COPY_ENGINE 4 /* stage the period with memcpy nodes instead of copy kernels */
+int bfhip_engine_rt_begin(bfhip_engine *e, int flags);
+int bfhip_engine_rt_end(bfhip_engine *e);
+/* the pinned buffers (io 0 = in, 1 = out; index 0/1): period k uses index k & 1.  A host that
+   fills / drains them in place passes NULL to rt_submit / rt_wait and saves both memcpys. */
+void *bfhip_engine_rt_buffer(bfhip_engine *e, int io, int index);
+/* start one period; returns at once.  At most two periods may be in flight. */
+int bfhip_engine_rt_submit(bfhip_engine *e, const void *rawin);
+/* wait for the oldest period in flight; returns its status bits (>= 0) like bfhip_engine_block.
+   overflow[] (n_out structs, may be NULL) receives the device's running overflow state. */
+int bfhip_engine_rt_wait(bfhip_engine *e, void *rawout, bfhip_overflow overflow[]);
+/* rt_submit + rt_wait */
+int bfhip_engine_rt_block(bfhip_engine *e, const void *rawin, void *rawout, bfhip_overflow overflow[]);
+/* how many periods were replayed from a graph / launched directly, and how many captures ran */
+int bfhip_engine_rt_stats(const bfhip_engine *e, unsigned long long *graph_blocks,
+                          unsigned long long *direct_blocks, unsigned long long *captures);
+
+
 /* before finalize: -1 = decide from the plan (default), 0 = the three kernels of a block on one
    stream, 1 = on three engine-owned streams (see bfhip_engine_block_dev) */
 int bfhip_engine_set_overlap(bfhip_engine *e, int mode);

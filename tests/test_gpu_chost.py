@@ -47,3 +47,22 @@ def test_c_host_file_to_file(hip, tmp_path):
         want.append(out.view(np.int32).reshape(L, O))
     want = np.concatenate(want)[:raw.shape[0]]
     assert np.abs(got.astype(np.int64) - want).max() <= 1
+
+
+def test_c_host_realtime_round_trip(hip):
+    """examples/bflatency.c: the same periods through bfhip_engine_block and the three real-time
+    variants from plain C; outputs must be byte-identical and the replayed path must not be
+    slower than the plain one (the latency numbers themselves are in profiles/)."""
+    import json
+    exe = os.path.join(ROOT, "examples", "bflatency")
+    subprocess.check_call(["gcc", "-O2", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "bflatency.c"), "-o", exe,
+                           "-L" + os.path.join(ROOT, "brutefir_amd"), "-lbfhip", "-lm",
+                           "-Wl,-rpath," + os.path.join(ROOT, "brutefir_amd")])
+    r = subprocess.run([exe, "300"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) >= 6
+    for ln in lines:
+        assert ln["outputs_identical"] is True, ln
+        assert ln["rt_spin"][0] <= ln["block"][0] * 1.1, ln
