@@ -186,6 +186,7 @@ struct bfhip_engine {
     DevFormat *d_fmt[2] = {nullptr, nullptr};
     DevOverflow *d_over = nullptr;
     int *d_status = nullptr;
+    int *d_status_own = nullptr;   // the engine's allocation while d_status points at a caller's word
     int *d_bad = nullptr;
     void *d_Zp = nullptr;          // [n_chunks][n_out_padded][L] complex
     size_t zp_bytes = 0;
@@ -1240,6 +1241,7 @@ void bfhip_engine_destroy(bfhip_engine *e) {
     }
     if (e->s_in) (void)hipStreamDestroy(e->s_in);
     if (e->s_out) (void)hipStreamDestroy(e->s_out);
+    if (e->d_status_own) e->d_status = e->d_status_own;
     void *ptrs[] = {e->d_tw, e->d_prev, e->d_ring, e->d_fmt[0], e->d_fmt[1], e->d_over, e->d_status,
                     e->d_bad, e->d_Zp, e->d_entries, e->d_chunks, e->d_rawin, e->d_rawout, e->d_taps,
                     e->d_fring, e->d_Y, e->d_Yold, e->d_evalprev, e->d_jobs,
@@ -1990,6 +1992,16 @@ int bfhip_engine_rt_stats(const bfhip_engine *e, unsigned long long *graph_block
     if (graph_blocks) *graph_blocks = e->rt.n_graph;
     if (direct_blocks) *direct_blocks = e->rt.n_direct;
     if (captures) *captures = e->rt.n_capture;
+    return BFHIP_OK;
+}
+
+int bfhip_engine_set_status_dev(bfhip_engine *e, int *status_dev) {
+    if (!e || !e->finalized) return fail(BFHIP_ESTATE, "set_status_dev: engine not finalized");
+    HIPCHK(hipSetDevice(e->device));
+    { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
+    if (!e->d_status_own) e->d_status_own = e->d_status;
+    e->d_status = status_dev ? status_dev : e->d_status_own;
+    e->rt.valid[0] = e->rt.valid[1] = false;
     return BFHIP_OK;
 }
 

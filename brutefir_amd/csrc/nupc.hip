@@ -15,11 +15,17 @@
 // frames of output block b are requantised out of the ring.  A contribution is in time iff
 //     off_k >= L_k - L_0
 // (checked at create); e.g. 2 x 64, 2 x 128, ... doubling satisfies it with equality + L_0.
-// All segments of a step are computed at the step (no spreading over earlier steps: this is a
-// throughput/latency engine, the real-time scheduling of the long segments is the host's).
+// A segment that starts later than it has to (slack = off_k - (L_k - L_0) > 0 frames; one period
+// for every segment but the first in the "two blocks per size, doubling" schedule, L_k - L_0
+// at most) does not have to be finished within the period it is launched in: it runs on its
+// own low-priority stream beside the periods that follow, and the main stream only waits for
+// it in the period its first output frame is due.  So the worst period costs about as much
+// as the common one, which is what real-time use needs.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -50,7 +56,7 @@ __global__ __launch_bounds__(256) void
 nupc_emit_kernel(T *__restrict__ acc, unsigned long long pos, int A, int n_out, int L0,
                  const DevFormat *__restrict__ fmt, const double *__restrict__ inv_scale,
                  DevOverflow *__restrict__ over, uint8_t *__restrict__ raw, double safety_limit,
-                 int *__restrict__ status) {
+                 int *__restrict__ status, unsigned int *__restrict__ arrive, int *__restrict__ host_status) {
     __shared__ unsigned int red_n[4];
     __shared__ int32_t red_i[4];
     __shared__ double red_l[4];
@@ -119,6 +125,15 @@ nupc_emit_kernel(T *__restrict__ acc, unsigned long long pos, int A, int n_out, 
         over[ch].intlargest = intlargest;
         over[ch].largest = largest;
         if (st) atomicOr(status, st);
+        // the last channel to finish hands the status bits of all segments (they OR into the
+        // same word) to the host's pinned word: no device-to-host copy after the sync
+        __threadfence();
+        if (atomicAdd(arrive, 1u) + 1u == gridDim.x) {
+            *arrive = 0;
+            const int bits = atomicExch(status, 0);
+            if (bits) *host_status = *host_status | bits;
+            __threadfence_system();
+        }
     }
 }
 
@@ -143,6 +158,13 @@ struct Seg {
     long off = 0;               // first tap this segment covers
     bfhip_engine *eng = nullptr;
     void *d_out = nullptr;      // [L][n_out] reals
+    // background execution (delay_steps > 0): launched on `stream`, added to the accumulator
+    // by the main stream delay_steps periods later
+    int delay_steps = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_done = nullptr, ev_consumed = nullptr;
+    bool pending = false, consumed_once = false;
+    unsigned long long pending_pos = 0, due_block = 0;
 };
 
 }  // namespace
@@ -154,7 +176,14 @@ struct bfhip_nupc {
     double safety_limit = 0;
     bool finalized = false;
     unsigned long long block = 0;          // L0-blocks processed
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;          // main stream: I/O, zero-slack segments, accumulate, emit
+    hipEvent_t ev_in = nullptr;            // this period's frames are in the input ring
+    int in_frames = 0;                     // input ring length: 2 * Lmax
+    unsigned int *d_arrive = nullptr;
+    int *h_status = nullptr;               // pinned
+    uint8_t *h_in = nullptr, *h_out = nullptr;   // pinned staging of one period (bfhip_nupc_block)
+    DevOverflow *h_over = nullptr;         // pinned
+    bool background = true;
     int A = 0;                             // accumulator ring length in frames
     void *d_acc = nullptr;                 // [A][n_out] reals
     uint8_t *d_in = nullptr;               // raw input ring: Lmax frames
@@ -213,9 +242,21 @@ void bfhip_nupc_destroy(bfhip_nupc *n) {
     if (!n) return;
     (void)hipSetDevice(n->device);
     if (n->stream) (void)hipStreamSynchronize(n->stream);
-    for (auto &s : n->seg) { if (s.eng) bfhip_engine_destroy(s.eng); if (s.d_out) (void)hipFree(s.d_out); }
-    void *p[] = {n->d_acc, n->d_in, n->d_rawout, n->d_fmt_out, n->d_inv_scale, n->d_over, n->d_status};
+    for (auto &s : n->seg) if (s.stream) (void)hipStreamSynchronize(s.stream);
+    for (auto &s : n->seg) {
+        if (s.eng) bfhip_engine_destroy(s.eng);
+        if (s.d_out) (void)hipFree(s.d_out);
+        if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+        if (s.ev_consumed) (void)hipEventDestroy(s.ev_consumed);
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+    }
+    void *p[] = {n->d_acc, n->d_in, n->d_rawout, n->d_fmt_out, n->d_inv_scale, n->d_over, n->d_status, n->d_arrive};
     for (void *q : p) if (q) (void)hipFree(q);
+    if (n->h_status) (void)hipHostFree(n->h_status);
+    if (n->h_in) (void)hipHostFree(n->h_in);
+    if (n->h_out) (void)hipHostFree(n->h_out);
+    if (n->h_over) (void)hipHostFree(n->h_over);
+    if (n->ev_in) (void)hipEventDestroy(n->ev_in);
     if (n->stream) (void)hipStreamDestroy(n->stream);
     delete n;
 }
@@ -261,7 +302,11 @@ int bfhip_nupc_finalize(bfhip_nupc *n) {
     if (!n) return nfail(BFHIP_EINVAL, "null");
     if (n->finalized) return BFHIP_OK;
     NCHK(hipSetDevice(n->device));
-    NCHK(hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking));
+    int prio_least = 0, prio_greatest = 0;
+    NCHK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    NCHK(hipStreamCreateWithPriority(&n->stream, hipStreamNonBlocking, prio_greatest));
+    NCHK(hipEventCreateWithFlags(&n->ev_in, hipEventDisableTiming));
+    if (const char *bg = getenv("BFHIP_NUPC_BACKGROUND")) n->background = atoi(bg) != 0;
     for (int io = 0; io < 2; io++) {
         const int c = io ? n->n_out : n->n_in;
         const int spacing = n->fmt[io][0].sample_spacing, bytes = n->fmt[io][0].bytes;
@@ -278,8 +323,11 @@ int bfhip_nupc_finalize(bfhip_nupc *n) {
     n->A = A;
     NCHK(hipMalloc(&n->d_acc, (size_t)A * n->n_out * n->rs));
     NCHK(hipMemset(n->d_acc, 0, (size_t)A * n->n_out * n->rs));
-    NCHK(hipMalloc((void **)&n->d_in, (size_t)Lmax * n->frame_bytes[0]));
-    NCHK(hipMemset(n->d_in, 0, (size_t)Lmax * n->frame_bytes[0]));
+    // two periods of the longest segment: its forward transform may still be reading one while
+    // the next is being filled
+    n->in_frames = 2 * Lmax;
+    NCHK(hipMalloc((void **)&n->d_in, (size_t)n->in_frames * n->frame_bytes[0]));
+    NCHK(hipMemset(n->d_in, 0, (size_t)n->in_frames * n->frame_bytes[0]));
     NCHK(hipMalloc((void **)&n->d_rawout, (size_t)L0 * n->frame_bytes[1]));
     NCHK(hipMemset(n->d_rawout, 0, (size_t)L0 * n->frame_bytes[1]));
     std::vector<DevFormat> df(n->n_out);
@@ -301,6 +349,13 @@ int bfhip_nupc_finalize(bfhip_nupc *n) {
     NCHK(hipMemcpy(n->d_over, ov.data(), ov.size() * sizeof(DevOverflow), hipMemcpyHostToDevice));
     NCHK(hipMalloc((void **)&n->d_status, sizeof(int)));
     NCHK(hipMemset(n->d_status, 0, sizeof(int)));
+    NCHK(hipMalloc((void **)&n->d_arrive, sizeof(unsigned int)));
+    NCHK(hipMemset(n->d_arrive, 0, sizeof(unsigned int)));
+    NCHK(hipHostMalloc((void **)&n->h_status, sizeof(int), hipHostMallocDefault));
+    NCHK(hipHostMalloc((void **)&n->h_in, (size_t)L0 * n->frame_bytes[0], hipHostMallocDefault));
+    NCHK(hipHostMalloc((void **)&n->h_out, (size_t)L0 * n->frame_bytes[1], hipHostMallocDefault));
+    NCHK(hipHostMalloc((void **)&n->h_over, (size_t)n->n_out * sizeof(DevOverflow), hipHostMallocDefault));
+    *n->h_status = 0;
     for (auto &s : n->seg) {
         for (int ch = 0; ch < n->n_in; ch++) ECHK(bfhip_engine_set_format(s.eng, BFHIP_IN, ch, &n->fmt[0][ch]));
         for (int ch = 0; ch < n->n_out; ch++) {
@@ -309,61 +364,105 @@ int bfhip_nupc_finalize(bfhip_nupc *n) {
             f.sample_spacing = n->n_out; f.byte_offset = ch * n->rs;
             ECHK(bfhip_engine_set_format(s.eng, BFHIP_OUT, ch, &f));
         }
-        ECHK(bfhip_engine_set_overlap(s.eng, 0));          // the segments are ordered on ONE stream
+        ECHK(bfhip_engine_set_overlap(s.eng, 0));          // a segment's kernels are ordered on ONE stream
         ECHK(bfhip_engine_finalize(s.eng));
-        ECHK(bfhip_engine_set_stream(s.eng, n->stream));
+        const long slack = s.off - ((long)s.L - L0);       // >= 0, checked at create
+        const long room = (long)s.L - L0;                  // its next block is launched L frames later
+        s.delay_steps = n->background ? (int)(std::min(slack, room) / L0) : 0;
+        if (s.delay_steps > 0) {
+            NCHK(hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, prio_least));
+            NCHK(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
+            NCHK(hipEventCreateWithFlags(&s.ev_consumed, hipEventDisableTiming));
+        }
+        ECHK(bfhip_engine_set_stream(s.eng, s.delay_steps > 0 ? s.stream : n->stream));
+        ECHK(bfhip_engine_set_status_dev(s.eng, n->d_status));
         NCHK(hipMalloc(&s.d_out, (size_t)s.L * n->n_out * n->rs));
     }
     n->finalized = true;
     return BFHIP_OK;
 }
 
+}  // extern "C"
+
+namespace {
+
+int nupc_accumulate(bfhip_nupc *n, const Seg &s, unsigned long long pos) {
+    const size_t cnt = (size_t)s.L * n->n_out;
+    if (n->rs == 4)
+        hipLaunchKernelGGL(nupc_accumulate_kernel<float>, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, n->stream,
+                           (float *)n->d_acc, (const float *)s.d_out, pos, n->A, n->n_out, s.L);
+    else
+        hipLaunchKernelGGL(nupc_accumulate_kernel<double>, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, n->stream,
+                           (double *)n->d_acc, (const double *)s.d_out, pos, n->A, n->n_out, s.L);
+    NCHK(hipGetLastError());
+    return BFHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 // one I/O block of L_0 frames, device-resident raw buffers, asynchronous on the nupc's stream
 int bfhip_nupc_block_dev(bfhip_nupc *n, const void *rawin_dev, void *rawout_dev) {
     if (!n || !n->finalized) return nfail(BFHIP_ESTATE, "nupc not finalized");
     NCHK(hipSetDevice(n->device));
-    const int L0 = n->seg[0].L, Lmax = n->seg.back().L;
+    const int L0 = n->seg[0].L;
     const unsigned long long end = (n->block + 1) * (unsigned long long)L0;       // samples received
-    // append to the input ring (linear inside one Lmax period: segment blocks are aligned)
-    const size_t wpos = (size_t)((end - L0) % (unsigned long long)Lmax);
+    // append to the input ring (segment blocks are aligned: never split by the wrap)
+    const size_t wpos = (size_t)((end - L0) % (unsigned long long)n->in_frames);
     if ((const uint8_t *)rawin_dev != n->d_in + wpos * n->frame_bytes[0])     // block() uploads straight into the slot
         NCHK(hipMemcpyAsync(n->d_in + wpos * n->frame_bytes[0], rawin_dev, (size_t)L0 * n->frame_bytes[0], hipMemcpyDeviceToDevice, n->stream));
+    bool ev_in_recorded = false;
     for (auto &s : n->seg) {
         if (end % (unsigned long long)s.L != 0) continue;
-        const size_t rpos = (size_t)((end - s.L) % (unsigned long long)Lmax);
-        ECHK(bfhip_engine_block_dev(s.eng, n->d_in + rpos * n->frame_bytes[0], s.d_out));
-        const size_t cnt = (size_t)s.L * n->n_out;
+        const size_t rpos = (size_t)((end - s.L) % (unsigned long long)n->in_frames);
         const unsigned long long pos = end - s.L + (unsigned long long)s.off;
-        if (n->rs == 4)
-            hipLaunchKernelGGL(nupc_accumulate_kernel<float>, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, n->stream,
-                               (float *)n->d_acc, (const float *)s.d_out, pos, n->A, n->n_out, s.L);
-        else
-            hipLaunchKernelGGL(nupc_accumulate_kernel<double>, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, n->stream,
-                               (double *)n->d_acc, (const double *)s.d_out, pos, n->A, n->n_out, s.L);
-        NCHK(hipGetLastError());
+        if (s.delay_steps == 0) {
+            ECHK(bfhip_engine_block_dev(s.eng, n->d_in + rpos * n->frame_bytes[0], s.d_out));
+            { const int r = nupc_accumulate(n, s, pos); if (r < 0) return r; }
+            continue;
+        }
+        if (s.pending) return nfail(BFHIP_ESTATE, "nupc: a background segment block was never collected");
+        if (!ev_in_recorded) { NCHK(hipEventRecord(n->ev_in, n->stream)); ev_in_recorded = true; }
+        NCHK(hipStreamWaitEvent(s.stream, n->ev_in, 0));
+        if (s.consumed_once) NCHK(hipStreamWaitEvent(s.stream, s.ev_consumed, 0));   // d_out is free again
+        ECHK(bfhip_engine_block_dev(s.eng, n->d_in + rpos * n->frame_bytes[0], s.d_out));
+        NCHK(hipEventRecord(s.ev_done, s.stream));
+        s.pending = true;
+        s.pending_pos = pos;
+        s.due_block = n->block + (unsigned long long)s.delay_steps;
+    }
+    for (auto &s : n->seg) {
+        if (!s.pending || s.due_block != n->block) continue;
+        NCHK(hipStreamWaitEvent(n->stream, s.ev_done, 0));
+        { const int r = nupc_accumulate(n, s, s.pending_pos); if (r < 0) return r; }
+        NCHK(hipEventRecord(s.ev_consumed, n->stream));
+        s.pending = false;
+        s.consumed_once = true;
     }
     const unsigned long long opos = end - L0;
     if (n->rs == 4)
         hipLaunchKernelGGL(nupc_emit_kernel<float>, dim3(n->n_out), dim3(256), 0, n->stream, (float *)n->d_acc, opos, n->A, n->n_out, L0,
-                           n->d_fmt_out, n->d_inv_scale, n->d_over, (uint8_t *)rawout_dev, n->safety_limit, n->d_status);
+                           n->d_fmt_out, n->d_inv_scale, n->d_over, (uint8_t *)rawout_dev, n->safety_limit, n->d_status,
+                           n->d_arrive, n->h_status);
     else
         hipLaunchKernelGGL(nupc_emit_kernel<double>, dim3(n->n_out), dim3(256), 0, n->stream, (double *)n->d_acc, opos, n->A, n->n_out, L0,
-                           n->d_fmt_out, n->d_inv_scale, n->d_over, (uint8_t *)rawout_dev, n->safety_limit, n->d_status);
+                           n->d_fmt_out, n->d_inv_scale, n->d_over, (uint8_t *)rawout_dev, n->safety_limit, n->d_status,
+                           n->d_arrive, n->h_status);
     NCHK(hipGetLastError());
     n->block++;
     return BFHIP_OK;
 }
 
+// waits for the periods handed in so far (NOT for background segment blocks that are not due
+// yet) and returns the status bits collected since the last call
 int bfhip_nupc_sync(bfhip_nupc *n) {
     if (!n || !n->finalized) return nfail(BFHIP_ESTATE, "nupc not finalized");
     NCHK(hipSetDevice(n->device));
     NCHK(hipStreamSynchronize(n->stream));
-    int st = 0;
-    for (auto &s : n->seg) { const int r = bfhip_engine_sync(s.eng); if (r < 0) return nfail(r, bfhip_last_error()); st |= r; }
-    int own = 0;
-    NCHK(hipMemcpy(&own, n->d_status, sizeof(int), hipMemcpyDeviceToHost));
-    if (own) NCHK(hipMemset(n->d_status, 0, sizeof(int)));
-    return st | own;
+    const int st = *(volatile int *)n->h_status;
+    *n->h_status = 0;
+    return st;
 }
 
 // host buffers: copies in, runs, copies out, waits; returns status bits
@@ -373,15 +472,24 @@ int bfhip_nupc_block(bfhip_nupc *n, const void *rawin, void *rawout, bfhip_overf
     const int L0 = n->seg[0].L;
     // upload straight into this block's slot of the input ring
     const unsigned long long end = (n->block + 1) * (unsigned long long)L0;
-    const size_t wpos = (size_t)((end - L0) % (unsigned long long)n->seg.back().L);
+    const size_t wpos = (size_t)((end - L0) % (unsigned long long)n->in_frames);
     uint8_t *slot = n->d_in + wpos * n->frame_bytes[0];
-    NCHK(hipMemcpyAsync(slot, rawin, (size_t)L0 * n->frame_bytes[0], hipMemcpyHostToDevice, n->stream));
-    if (overflow) NCHK(hipMemcpyAsync(n->d_over, overflow, n->n_out * sizeof(DevOverflow), hipMemcpyHostToDevice, n->stream));
+    // through pinned staging buffers: copies from pageable memory stall in the runtime every so often
+    memcpy(n->h_in, rawin, (size_t)L0 * n->frame_bytes[0]);
+    NCHK(hipMemcpyAsync(slot, n->h_in, (size_t)L0 * n->frame_bytes[0], hipMemcpyHostToDevice, n->stream));
+    if (overflow) {
+        memcpy(n->h_over, overflow, n->n_out * sizeof(DevOverflow));
+        NCHK(hipMemcpyAsync(n->d_over, n->h_over, n->n_out * sizeof(DevOverflow), hipMemcpyHostToDevice, n->stream));
+    }
     int r = bfhip_nupc_block_dev(n, slot, n->d_rawout);
     if (r < 0) return r;
-    NCHK(hipMemcpyAsync(rawout, n->d_rawout, (size_t)L0 * n->frame_bytes[1], hipMemcpyDeviceToHost, n->stream));
-    if (overflow) NCHK(hipMemcpyAsync(overflow, n->d_over, n->n_out * sizeof(DevOverflow), hipMemcpyDeviceToHost, n->stream));
-    return bfhip_nupc_sync(n);
+    NCHK(hipMemcpyAsync(n->h_out, n->d_rawout, (size_t)L0 * n->frame_bytes[1], hipMemcpyDeviceToHost, n->stream));
+    if (overflow) NCHK(hipMemcpyAsync(n->h_over, n->d_over, n->n_out * sizeof(DevOverflow), hipMemcpyDeviceToHost, n->stream));
+    r = bfhip_nupc_sync(n);
+    if (r < 0) return r;
+    memcpy(rawout, n->h_out, (size_t)L0 * n->frame_bytes[1]);
+    if (overflow) memcpy(overflow, n->h_over, n->n_out * sizeof(DevOverflow));
+    return r;
 }
 
 int bfhip_nupc_get_overflow(bfhip_nupc *n, int ch, bfhip_overflow *of) {

@@ -224,6 +224,12 @@ int bfhip_engine_rt_stats(const bfhip_engine *e, unsigned long long *graph_block
                           unsigned long long *direct_blocks, unsigned long long *captures);
 
 
+/* Several engines that make up one filter (the segments of include/bfhip_nupc.h) can report into
+   one status word in device memory: the NaN/Inf and safety-limit bits (real2raw.h:24-41) are
+   OR-ed into *status_dev instead of the engine's own word, and reading / clearing it is the
+   caller's business (bfhip_engine_sync then reads that word).  NULL restores the own word. */
+int bfhip_engine_set_status_dev(bfhip_engine *e, int *status_dev);
+
 /* before finalize: -1 = decide from the plan (default), 0 = the three kernels of a block on one
    stream, 1 = on three engine-owned streams (see bfhip_engine_block_dev) */
 int bfhip_engine_set_overlap(bfhip_engine *e, int mode);
