@@ -1201,14 +1201,11 @@ bfhip_engine *bfhip_engine_create(int device, int length, int n_blocks, int real
     }
     bool ok = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) == hipSuccess;
     e->own_stream = ok;
-    // twiddles exp(-2 pi i m / (2L)), computed in double
-    const size_t ntw = (size_t)2 * length;
-    std::vector<unsigned char> tw(ntw * e->csize());
-    for (size_t m = 0; m < ntw; m++) {
-        const double a = -M_PI * (double)m / (double)length;
-        if (realsize == 4) { ((float *)tw.data())[2 * m] = (float)cos(a); ((float *)tw.data())[2 * m + 1] = (float)sin(a); }
-        else { ((double *)tw.data())[2 * m] = cos(a); ((double *)tw.data())[2 * m + 1] = sin(a); }
-    }
+    // twiddles exp(-2 pi i m / (2L)), computed in double, + their thread-ordered copy (fft_lds.h)
+    int log2l = 0;
+    while ((1 << log2l) < length) log2l++;
+    const std::vector<unsigned char> tw = make_twiddle_table(log2l, realsize,
+        realsize == 4 ? fft_threads<float>(log2l) : fft_threads<double>(log2l));
     ok = ok && hipMalloc(&e->d_tw, tw.size()) == hipSuccess;
     ok = ok && hipMemcpy(e->d_tw, tw.data(), tw.size(), hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_bad, sizeof(int)) == hipSuccess;

@@ -380,13 +380,8 @@ void *scratch(int i, size_t bytes) {
 const void *twiddles(int log2c) {
     auto it = G.tw.find(log2c);
     if (it != G.tw.end()) return it->second;
-    const size_t Lc = (size_t)1 << log2c, n = 2 * Lc;
-    std::vector<unsigned char> h(n * 2 * G.rs);
-    for (size_t m = 0; m < n; m++) {
-        const double a = -M_PI * (double)m / (double)Lc;
-        if (G.rs == 4) { ((float *)h.data())[2 * m] = (float)cos(a); ((float *)h.data())[2 * m + 1] = (float)sin(a); }
-        else { ((double *)h.data())[2 * m] = cos(a); ((double *)h.data())[2 * m + 1] = sin(a); }
-    }
+    const std::vector<unsigned char> h = make_twiddle_table(log2c, G.rs,
+        G.rs == 4 ? fft_threads<float>(log2c) : fft_threads<double>(log2c));
     void *d = nullptr;
     if (hipMalloc(&d, h.size()) != hipSuccess || hipMemcpy(d, h.data(), h.size(), hipMemcpyHostToDevice) != hipSuccess) {
         fatal(103, "bfhip: twiddle upload failed");

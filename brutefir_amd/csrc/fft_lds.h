@@ -26,6 +26,14 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cmath>
+#include <vector>
+
+// phase markers for tools/fft_probe.hip (cycle stamps of one wave); nothing in the product build
+#ifndef BF_PROBE
+#define BF_PROBE(i)
+#endif
+
 namespace bfhip {
 
 template <typename T> struct alignas(2 * sizeof(T)) c2 { T x, y; };
@@ -92,7 +100,11 @@ constexpr int tw_total(int log2l, int nt, int log2ns) {
 }
 
 // The twiddles of every pass for this thread, in registers.
-// tw = exp(-2 pi i m / (2L)), m in [0, 2L), in global memory.
+// Twiddle table in global memory (make_twiddle_table below): entries [0, 2L) are
+// exp(-2 pi i m / (2L)); behind them the same values again in THREAD ORDER -- entry
+// 2L + q*NT + tid is register q of thread tid -- so that a wave fetches each register with one
+// contiguous 512-byte load instead of a 64-line gather (the gathers of 16 waves kept the CU's
+// texture path busy for ~3 us of a 17 us transform at L = 8192).
 template <typename T, int LOG2L, int NT> struct TwRegs {
     static constexpr int N = tw_total(LOG2L, NT, 0) > 0 ? tw_total(LOG2L, NT, 0) : 1;
     c2<T> r[N];
@@ -107,11 +119,10 @@ template <typename T, int LOG2L, int NT> struct TwRegs {
             if constexpr (NTW > 0) {
 #pragma unroll
                 for (int b = 0; b < B; b++) {
-                    const int j = threadIdx.x + b * NT;
-                    const int k = (TT % NT == 0 || j < TT) ? (j & (Ns - 1)) : 0;
 #pragma unroll
-                    for (int i = 0; i < NTW; i++) r[OFF + b * NTW + i] = tw[(k << i) * TWSTEP];
+                    for (int i = 0; i < NTW; i++) r[OFF + b * NTW + i] = tw[2 * L + (OFF + b * NTW + i) * NT + (int)threadIdx.x];
                 }
+                (void)TT; (void)Ns; (void)TWSTEP;
             }
             fetch_from<LOG2NS + LOG2R, OFF + B * NTW>(tw);
         }
@@ -172,6 +183,7 @@ __device__ __forceinline__ void fft_passes(LdsArr<T> s, const TwRegs<T, LOG2L, N
     if constexpr (LOG2NS < LOG2L) {
         constexpr int LOG2R = pass_log2r(LOG2L, LOG2NS);
         fft_pass<T, LOG2L, NT, INV, LOG2NS, OFF>(s, tw);
+        BF_PROBE(4 + LOG2NS / 3);
         fft_passes<T, LOG2L, NT, INV, LOG2NS + LOG2R, OFF + pass_b(LOG2L, NT, LOG2NS) * pass_ntw(LOG2L, LOG2NS)>(s, tw);
     }
 }
@@ -181,6 +193,37 @@ __device__ __forceinline__ void fft_passes(LdsArr<T> s, const TwRegs<T, LOG2L, N
 template <typename T, int LOG2L, int NT, bool INV>
 __device__ __forceinline__ void lds_fft(LdsArr<T> s, const TwRegs<T, LOG2L, NT> &tw) {
     fft_passes<T, LOG2L, NT, INV, 0, 0>(s, tw);
+}
+
+// Host: the table TwRegs::prefetch and the real-transform (un)tangling read, for the NT the
+// kernels of this precision use.  Values are computed in double and rounded once.
+inline std::vector<unsigned char> make_twiddle_table(int log2l, int realsize, int nt) {
+    const size_t L = (size_t)1 << log2l;
+    const size_t n_regs = (size_t)tw_total(log2l, nt, 0);
+    const size_t total = 2 * L + n_regs * (size_t)nt;
+    std::vector<unsigned char> out(total * 2 * (size_t)realsize);
+    auto put = [&](size_t idx, size_t m) {
+        const double a = -M_PI * (double)m / (double)L;
+        if (realsize == 4) { ((float *)out.data())[2 * idx] = (float)std::cos(a); ((float *)out.data())[2 * idx + 1] = (float)std::sin(a); }
+        else { ((double *)out.data())[2 * idx] = std::cos(a); ((double *)out.data())[2 * idx + 1] = std::sin(a); }
+    };
+    for (size_t m = 0; m < 2 * L; m++) put(m, m);
+    size_t q = 0;
+    for (int log2ns = 0; log2ns < log2l; log2ns += pass_log2r(log2l, log2ns)) {
+        const int log2r = pass_log2r(log2l, log2ns);
+        const int R = 1 << log2r, Ns = 1 << log2ns, TT = (int)L / R;
+        const int B = pass_b(log2l, nt, log2ns), NTW = pass_ntw(log2l, log2ns);
+        const int twstep = (int)(2 * L) / (Ns * R);
+        for (int b = 0; b < B; b++)
+            for (int i = 0; i < NTW; i++)
+                for (int tid = 0; tid < nt; tid++) {
+                    const int j = tid + b * nt;
+                    const int k = (TT % nt == 0 || j < TT) ? (j & (Ns - 1)) : 0;
+                    put(2 * L + (q + (size_t)b * NTW + i) * (size_t)nt + tid, (size_t)(k << i) * twstep);
+                }
+        q += (size_t)B * NTW;
+    }
+    return out;
 }
 
 // threads per workgroup used for a transform of 2^LOG2L complex points: one radix-8 butterfly
