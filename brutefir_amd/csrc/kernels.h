@@ -854,27 +854,49 @@ ifft_out_body(int zi /* index into Zp's channel axis */, unsigned char *smem,
     const int ch = first_channel + zi;         // output channel
     const c2<T> *z = Zp + (size_t)zi * L;
 
-    TwRegs<T, LOG2L, NT> twr;
-    twr.prefetch(tw);
-    c2<T> uw[QU], za[QU], zb[QU];
-    c2<T> z0 = mk<T>((T)0, (T)0);
+    // Everything the kernel will need from global memory is requested up front, the spectra
+    // first (loads return in order: the sum and the LDS fill then only wait for those), the
+    // channel's format and overflow state last (they are needed after the transform).
+    c2<T> uw[QU], za[QU], zb[QU], ta[QU], tb[QU];
+    c2<T> z0 = mk<T>((T)0, (T)0), t0 = mk<T>((T)0, (T)0);
 #pragma unroll
-    for (int i = 0; i < QU; i++) { const int k = 1 + tid + i * NT; uw[i] = tw[k <= L / 2 ? k : 0]; }
-    // chunk partials: all loads of one chunk are in flight together, chunks add up in order
-    for (int c = 0; c < n_chunks; c++) {
-        const c2<T> *zc = z + (size_t)c * chunk_stride;
-        c2<T> ta[QU], tb[QU];
+    for (int i = 0; i < QU; i++) {
+        const int k = 1 + tid + i * NT;
+        if (k <= L / 2) { za[i] = z[k]; zb[i] = z[L - k]; }
+    }
+    if (tid == 0) z0 = z[0];
+    if (n_chunks > 1) {
+        const c2<T> *zc = z + chunk_stride;
 #pragma unroll
         for (int i = 0; i < QU; i++) {
             const int k = 1 + tid + i * NT;
             if (k <= L / 2) { ta[i] = zc[k]; tb[i] = zc[L - k]; }
         }
-        if (tid == 0) { const c2<T> t0 = zc[0]; z0 = c == 0 ? t0 : z0 + t0; }
+        if (tid == 0) t0 = zc[0];
+    }
+    TwRegs<T, LOG2L, NT> twr;
+    twr.prefetch(tw);
+#pragma unroll
+    for (int i = 0; i < QU; i++) { const int k = 1 + tid + i * NT; uw[i] = tw[k <= L / 2 ? k : 0]; }
+    const DevFormat f = fmt[ch];
+    DevOverflow of = over[ch];
+    const bool quant = skip_quant == nullptr || !skip_quant[ch];
+    // chunk partials add up in chunk order (deterministic)
+    if (n_chunks > 1) {
+        z0 = z0 + t0;
+#pragma unroll
+        for (int i = 0; i < QU; i++) { za[i] = za[i] + ta[i]; zb[i] = zb[i] + tb[i]; }
+    }
+    for (int c = 2; c < n_chunks; c++) {
+        const c2<T> *zc = z + (size_t)c * chunk_stride;
 #pragma unroll
         for (int i = 0; i < QU; i++) {
-            za[i] = c == 0 ? ta[i] : za[i] + ta[i];
-            zb[i] = c == 0 ? tb[i] : zb[i] + tb[i];
+            const int k = 1 + tid + i * NT;
+            if (k <= L / 2) { ta[i] = zc[k]; tb[i] = zc[L - k]; }
         }
+        if (tid == 0) { t0 = zc[0]; z0 = z0 + t0; }
+#pragma unroll
+        for (int i = 0; i < QU; i++) { za[i] = za[i] + ta[i]; zb[i] = zb[i] + tb[i]; }
     }
     if (tid == 0) s[0] = mk<T>(z0.x + z0.y, z0.x - z0.y);
 #pragma unroll
@@ -890,8 +912,6 @@ ifft_out_body(int zi /* index into Zp's channel axis */, unsigned char *smem,
     __syncthreads();
     lds_fft<T, LOG2L, NT, true>(s, twr);
 
-    const DevFormat f = fmt[ch];
-    DevOverflow of = over[ch];
     uint8_t *base = raw + f.byte_offset;
     const size_t stride = (size_t)f.sample_spacing * f.bytes;
     const int bits = f.sbytes << 3;
@@ -899,7 +919,6 @@ ifft_out_body(int zi /* index into Zp's channel axis */, unsigned char *smem,
     const int32_t imax = (int32_t)(((uint64_t)1 << (bits - 1)) - 1);
     const double rmin_i = (double)(T)imin, rmax_i = (double)(T)imax;
     const T rmin_f = (T)(-of.max), rmax_f = (T)of.max;
-    const bool quant = skip_quant == nullptr || !skip_quant[ch];
     unsigned int n_over = 0;
     int32_t intlargest = of.intlargest;
     double largest = of.largest;

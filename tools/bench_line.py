@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
-"""print the interesting fields of a bench.py JSON line (stdin)"""
+"""print the interesting fields of bench.py JSON lines (files given as arguments, else stdin)"""
 import json
 import sys
 
-for line in sys.stdin:
+import fileinput
+
+for line in fileinput.input():
     line = line.strip()
     if not line.startswith("{"):
         continue
