@@ -253,6 +253,7 @@ struct bfhip_engine {
     int n_groups = 0, n_out_padded = 0, n_chunks = 1, n_tiles = 1, mac_threads = 256;
     int n_entries = 0;
     bool mac_nt = true;            // non-temporal coefficient loads (BFHIP_MAC_NT=0 turns them off)
+    int mac_unroll = 3;            // partitions in flight per wave (BFHIP_MAC_UNROLL=1..4, tools/tune_mac.py)
     double alg_bytes_total = 0, alg_bytes_mac = 0;
 
     // real-time mode (bfhip_engine_rt_*): pinned host double buffer, the block's launch
@@ -397,16 +398,17 @@ void launch_mac(bfhip_engine *e, void *Zp, hipError_t *err) {
     const int tc8 = (n_tc + 7) / 8;
     const int grid = tc8 * e->n_groups * 8;
     const unsigned long long age64 = std::min<unsigned long long>(e->blocks_done + 1, (unsigned long long)e->N);
-    if (e->mac_nt)
-        hipLaunchKernelGGL((mac_xbar_kernel<T, true>), dim3(grid), dim3(e->mac_threads), 0, e->ls,
-                           (const MacEntry<T> *)e->d_entries, (const ChunkRange *)e->d_chunks,
-                           (c2<T> *)Zp, e->L, e->n_out_padded, e->n_groups, e->n_chunks, n_tc,
-                           e->blockcounter, (int)age64, (const BlockState *)e->bs_arg);
-    else
-        hipLaunchKernelGGL((mac_xbar_kernel<T, false>), dim3(grid), dim3(e->mac_threads), 0, e->ls,
-                           (const MacEntry<T> *)e->d_entries, (const ChunkRange *)e->d_chunks,
-                           (c2<T> *)Zp, e->L, e->n_out_padded, e->n_groups, e->n_chunks, n_tc,
-                           e->blockcounter, (int)age64, (const BlockState *)e->bs_arg);
+#define BFHIP_LAUNCH_MAC(NTFLAG, U)                                                                   \
+    hipLaunchKernelGGL((mac_xbar_kernel<T, NTFLAG, U>), dim3(grid), dim3(e->mac_threads), 0, e->ls,      \
+                       (const MacEntry<T> *)e->d_entries, (const ChunkRange *)e->d_chunks,               \
+                       (c2<T> *)Zp, e->L, e->n_out_padded, e->n_groups, e->n_chunks, n_tc,               \
+                       e->blockcounter, (int)age64, (const BlockState *)e->bs_arg)
+    if (!e->mac_nt) BFHIP_LAUNCH_MAC(false, 2);
+    else if (e->mac_unroll == 4) BFHIP_LAUNCH_MAC(true, 4);
+    else if (e->mac_unroll == 3) BFHIP_LAUNCH_MAC(true, 3);
+    else if (e->mac_unroll == 1) BFHIP_LAUNCH_MAC(true, 1);
+    else BFHIP_LAUNCH_MAC(true, 2);
+#undef BFHIP_LAUNCH_MAC
     *err = hipGetLastError();
 }
 
@@ -610,6 +612,7 @@ int build_plan_t(bfhip_engine *e) {
     int target_wgs = 256;
     if (const char *env = getenv("BFHIP_MAC_TARGET_WGS")) target_wgs = std::max(1, atoi(env));
     if (const char *env = getenv("BFHIP_MAC_NT")) e->mac_nt = atoi(env) != 0;
+    if (const char *env = getenv("BFHIP_MAC_UNROLL")) e->mac_unroll = atoi(env);
     const int s_full = std::max(1, std::min(64, (target_wgs + e->n_tiles * e->n_groups - 1) / (e->n_tiles * e->n_groups)));
     int S = s_full;
     if (!getenv("BFHIP_MAC_TARGET_WGS")) {

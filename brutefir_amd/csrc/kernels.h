@@ -385,7 +385,7 @@ __global__ void reorder_kernel(const T *__restrict__ q, c2<T> *__restrict__ pack
 // need the same ring tile get the same blockIdx%8 (one XCD, adjacent dispatch) so that the
 // ring re-reads hit that XCD's L2.  Partial sums of the chunks go to Zp[chunk][o][k] and
 // are added up by the consumer (K3 or sum_partials_kernel): deterministic, no atomics.
-template <typename T, bool NT>
+template <typename T, bool NT, int UNROLL = 2>
 __global__ __launch_bounds__(256) void
 mac_xbar_kernel(const MacEntry<T> *__restrict__ entries, const ChunkRange *__restrict__ chunks,
                 c2<T> *__restrict__ Zp, int L, int n_out_padded, int n_groups, int n_chunks,
@@ -426,7 +426,7 @@ mac_xbar_kernel(const MacEntry<T> *__restrict__ entries, const ChunkRange *__res
             T sc[OG];
 #pragma unroll
             for (int j = 0; j < OG; j++) { Hs[j] = E->term[j].H; sc[j] = E->term[j].scale; }
-#pragma unroll 2
+#pragma unroll UNROLL
             for (int p = p0; p < maxP; p++) {
                 // byte offsets kept in 32 bits (N * L * 16 < 4 GiB) so that the loads take the
                 // scalar-base + 32-bit lane-offset form

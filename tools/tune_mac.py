@@ -4,6 +4,8 @@ builds the config-C engine once, then for every round and every candidate rebuil
 plan with BFHIP_MAC_TARGET_WGS=<candidate> and times 40 steady-state blocks with HIP events.
 
     python tools/tune_mac.py 256 512 1024 2048 [--rounds 3]
+    python tools/tune_mac.py --env BFHIP_MAC_UNROLL 1 2 3 4      # same for another plan knob
+    python tools/tune_mac.py --grid 2:256 3:256 2:512 3:512      # unroll:target_wgs pairs
 """
 import os
 import sys
@@ -21,7 +23,12 @@ def main():
     if "--rounds" in sys.argv:
         rounds = int(sys.argv[sys.argv.index("--rounds") + 1])
         args = [a for a in args if a != str(rounds)] or args
-    cands = [int(a) for a in args] or [512, 1024, 2048]
+    knob = "BFHIP_MAC_TARGET_WGS"
+    if "--env" in sys.argv:
+        knob = sys.argv[sys.argv.index("--env") + 1]
+        args = [a for a in args if a != knob]
+    grid = "--grid" in sys.argv
+    cands = ([a for a in args if ":" in a] if grid else [int(a) for a in args]) or [512, 1024, 2048]
     I, O, L, N, rs, fmt = bench.WORKLOADS["C"]
     dev = torch.device("cuda", 0)
     eng = bf.Engine(L, N, rs, I, O)
@@ -42,7 +49,10 @@ def main():
     res = {c: [] for c in cands}
     for r in range(rounds):
         for c in cands:
-            os.environ["BFHIP_MAC_TARGET_WGS"] = str(c)
+            if grid:
+                os.environ["BFHIP_MAC_UNROLL"], os.environ["BFHIP_MAC_TARGET_WGS"] = c.split(":")
+            else:
+                os.environ[knob] = str(c)
             eng.set_delayblocks(0, 1)       # any control change marks the plan dirty ...
             eng.set_delayblocks(0, 0)       # ... and back: same plan, new geometry
             for k in range(4):
@@ -57,8 +67,8 @@ def main():
     for c in cands:
         mac = sorted(m for m, _ in res[c])
         tot = sorted(s for _, s in res[c])
-        print("target_wgs %5d: mac median %.4f ms (min %.4f) = %.0f GB/s | K1+K2+K3 median %.4f ms"
-              % (c, mac[len(mac) // 2], mac[0], alg / mac[len(mac) // 2] / 1e6, tot[len(tot) // 2]))
+        print((("grid " + c + "  ") if grid else knob + " %5d" % c) + ": mac median %.4f ms (min %.4f) = %.0f GB/s | K1+K2+K3 median %.4f ms"
+              % (mac[len(mac) // 2], mac[0], alg / mac[len(mac) // 2] / 1e6, tot[len(tot) // 2]))
 
 
 if __name__ == "__main__":
