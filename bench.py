@@ -165,9 +165,27 @@ def main():
     dev_index = local_rank % max(ndev, 1)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    fallback_note = ""
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        try:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            if backend == "nccl":                    # first collective = communicator set-up
+                probe = torch.ones(1, device=device)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+        except Exception as exc:                     # noqa: BLE001
+            if backend != "nccl":
+                raise
+            # never silently: the line says which transport carried the mix-down
+            sys.stderr.write("bench.py: RCCL not usable here (%s); mix-down over gloo host buffers instead\n" % exc)
+            try:
+                dist.destroy_process_group()
+            except Exception:                        # noqa: BLE001
+                pass
+            backend = "gloo"
+            fallback_note = " [RCCL failed to initialise: gloo host mix-down]"
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     wl = WORKLOADS[args.workload]
     I, O, L, N, rs, fmt = wl
@@ -298,8 +316,9 @@ def main():
                                                        I if args.workload in DIAGONAL else I * O),
                        "baseline_config": {"C": "configs[2]", "B": "configs[1]", "D": "configs[3] on one GPU",
                                            "E": "configs[4] (uniform partitions)"}.get(args.workload, "per-rank share of configs[2]"),
-                       "parallelism": ("input-sharded x%d + RCCL reduce-scatter%s"
-                                       % (world, " (overlapped with the next block)" if pipelined else ""))
+                       "parallelism": ("input-sharded x%d + %s reduce-scatter%s%s"
+                                       % (world, "RCCL" if backend == "nccl" else "gloo (host)",
+                                          " (overlapped with the next block)" if pipelined else "", fallback_note))
                                       if world > 1
                                       else "single GPU",
                        "status_bits": status},
