@@ -665,6 +665,11 @@ int build_plan_t(bfhip_engine *e) {
             bool dense = en.maxP > en.p0;
             for (int q = 0; q < OG; q++) dense = dense && en.term[q].kind == TERM_COEFF && en.term[q].P >= en.maxP;
             en.dense = dense ? 1 : 0;
+            // exactly one coefficient term (one-to-one filters, massive_config style): its own
+            // pipelined path, 2 + index of the term
+            int n_active = 0, only = -1;
+            for (int q = 0; q < OG; q++) if (en.term[q].kind != TERM_NONE) { n_active++; only = q; }
+            if (!dense && n_active == 1 && en.term[only].kind == TERM_COEFF && en.maxP > en.p0) en.dense = 2 + only;
         }
     }
 

@@ -418,7 +418,7 @@ mac_xbar_kernel(const MacEntry<T> *__restrict__ entries, const ChunkRange *__res
         const int p0 = E->p0;
         int maxP = E->maxP;
         if (maxP > age - delay) maxP = age - delay;     // blocks that exist yet (procblocks)
-        if (E->dense) {
+        if (E->dense == 1) {
             // The crossbar case: OG coefficient terms of equal length.  Per partition one ring
             // load and OG coefficient loads (1 KiB per wave each) are issued back to back from
             // wave-uniform bases + one shared lane offset, then accumulated as they land.
@@ -452,6 +452,44 @@ mac_xbar_kernel(const MacEntry<T> *__restrict__ entries, const ChunkRange *__res
                     }
                 }
             }
+            continue;
+        }
+        if (E->dense >= 2) {
+            // One coefficient term only (one-to-one filters): nothing to reuse, so the depth
+            // comes from four partitions (ring + coefficient tile each) in flight per wave.
+            const int js = E->dense - 2;
+            const c2<T> *H = E->term[js].H;
+            const T sc = E->term[js].scale;
+            if (maxP > E->term[js].P) maxP = E->term[js].P;
+            T ta[2 * V];
+#pragma unroll
+            for (int v = 0; v < 2 * V; v++) ta[v] = (T)0;
+#pragma unroll 4
+            for (int p = p0; p < maxP; p++) {
+                const unsigned int slot = (t - (unsigned int)p - (unsigned int)delay) % (unsigned int)R;
+                const unsigned int xoff = (slot * (unsigned int)L + (unsigned int)k0) * (unsigned int)sizeof(c2<T>);
+                const unsigned int hoff = ((unsigned int)p * (unsigned int)L + (unsigned int)k0) * (unsigned int)sizeof(c2<T>);
+                c2<T> x[V], h[V];
+                Load16<T, false>::get((const c2<T> *)((const char *)ring + xoff), x);
+                Load16<T, false>::get((const c2<T> *)((const char *)H + hoff), h);
+                {
+                    const T xr = x[0].x * sc, xi = x[0].y * sc;
+                    const T hsel = dc ? h[0].y : h[0].x;
+                    ta[0] += xr * h[0].x - (am * xi) * h[0].y;
+                    ta[1] += (am * xr) * h[0].y + xi * hsel;
+                }
+                if constexpr (V == 2) {
+                    const T xr = x[1].x * sc, xi = x[1].y * sc;
+                    ta[2] += xr * h[1].x - xi * h[1].y;
+                    ta[3] += xr * h[1].y + xi * h[1].x;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < OG; j++)
+                if (j == js) {
+#pragma unroll
+                    for (int v = 0; v < 2 * V; v++) acc[j][v] += ta[v];
+                }
             continue;
         }
         for (int p = p0; p < maxP; p++) {
