@@ -121,6 +121,7 @@ def lib():
     L.bfhip_engine_read_output_spectrum.argtypes = [vp, ci, vp]
     L.bfhip_engine_read_ring_slot.argtypes = [vp, ci, ci, vp]
     ull = C.POINTER(C.c_ulonglong)
+    L.bfhip_engine_prewarm.argtypes = [vp]
     L.bfhip_engine_rt_begin.argtypes = [vp, ci]
     L.bfhip_engine_rt_end.argtypes = [vp]
     L.bfhip_engine_rt_buffer.restype = vp
@@ -306,6 +307,9 @@ class Engine:
 
     def block_dev(self, rawin_dev, rawout_dev):
         _check(lib().bfhip_engine_block_dev(self.h, _ptr(rawin_dev), _ptr(rawout_dev)))
+
+    def prewarm(self):
+        _check(lib().bfhip_engine_prewarm(self.h))
 
     # real-time mode (callback I/O): pinned double buffer + graph replay
     def rt_begin(self, flags=0):

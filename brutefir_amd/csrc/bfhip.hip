@@ -2000,6 +2000,18 @@ int bfhip_engine_rt_stats(const bfhip_engine *e, unsigned long long *graph_block
     return BFHIP_OK;
 }
 
+int bfhip_engine_prewarm(bfhip_engine *e) {
+    int r = ensure_ready(e);
+    if (r != BFHIP_OK) return r;
+    if (e->blocks_done != 0) return fail(BFHIP_ESTATE, "prewarm: blocks have been processed already");
+    // N blocks of silence are what the zero-initialised rings hold: count them as processed, and
+    // move the block counter past the point where (blockcounter - p - delay) would wrap
+    e->blocks_done = (unsigned long long)e->N;
+    e->blockcounter = (unsigned int)e->R;
+    e->rt.bs_synced = false;
+    return BFHIP_OK;
+}
+
 int bfhip_engine_set_status_dev(bfhip_engine *e, int *status_dev) {
     if (!e || !e->finalized) return fail(BFHIP_ESTATE, "set_status_dev: engine not finalized");
     HIPCHK(hipSetDevice(e->device));

@@ -376,6 +376,30 @@ __global__ void reorder_kernel(const T *__restrict__ q, c2<T> *__restrict__ pack
 
 // ------------------------------------------------------------------ K2: crossbar MAC
 
+// acc += x * h, complex, as four explicit fused multiply-adds in a fixed order.  Written out
+// (rather than left to -ffp-contract) so that the unrolled body and the remainder of the
+// partition loop round identically: the result must not depend on how many partitions exist
+// yet during warm-up.  `am` is 0 for the lane that holds element 0 = (DC, Nyquist), whose two
+// components are real*real products (fftw_convfuns.h:545-559), else 1.
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+template <typename T>
+__device__ __forceinline__ void cmac_first(T &re, T &im, T xr, T xi, c2<T> h, T am, bool dc) {
+    const T hsel = dc ? h.y : h.x;
+    re = fma_t(xr, h.x, re);
+    re = fma_t(-(am * xi), h.y, re);
+    im = fma_t(am * xr, h.y, im);
+    im = fma_t(xi, hsel, im);
+}
+template <typename T>
+__device__ __forceinline__ void cmac(T &re, T &im, T xr, T xi, c2<T> h) {
+    re = fma_t(xr, h.x, re);
+    re = fma_t(-xi, h.y, re);
+    im = fma_t(xr, h.y, im);
+    im = fma_t(xi, h.x, im);
+}
+
+
 // Z[o][k] (+)= sum over entries (ring, delay) and partitions p of
 //              scale * ring[(t - p - delay) mod R][k] * H[p][k]
 // Work decomposition: workgroup = (bin tile, output group of OG, chunk of the group's
@@ -441,14 +465,11 @@ mac_xbar_kernel(const MacEntry<T> *__restrict__ entries, const ChunkRange *__res
                 for (int j = 0; j < OG; j++) {
                     {
                         const T xr = x[0].x * sc[j], xi = x[0].y * sc[j];
-                        const T hsel = dc ? h[j][0].y : h[j][0].x;
-                        acc[j][0] += xr * h[j][0].x - (am * xi) * h[j][0].y;
-                        acc[j][1] += (am * xr) * h[j][0].y + xi * hsel;
+                        cmac_first(acc[j][0], acc[j][1], xr, xi, h[j][0], am, dc);
                     }
                     if constexpr (V == 2) {
                         const T xr = x[1].x * sc[j], xi = x[1].y * sc[j];
-                        acc[j][2] += xr * h[j][1].x - xi * h[j][1].y;
-                        acc[j][3] += xr * h[j][1].y + xi * h[j][1].x;
+                        cmac(acc[j][2], acc[j][3], xr, xi, h[j][1]);
                     }
                 }
             }
@@ -474,14 +495,11 @@ mac_xbar_kernel(const MacEntry<T> *__restrict__ entries, const ChunkRange *__res
                 Load16<T, false>::get((const c2<T> *)((const char *)H + hoff), h);
                 {
                     const T xr = x[0].x * sc, xi = x[0].y * sc;
-                    const T hsel = dc ? h[0].y : h[0].x;
-                    ta[0] += xr * h[0].x - (am * xi) * h[0].y;
-                    ta[1] += (am * xr) * h[0].y + xi * hsel;
+                    cmac_first(ta[0], ta[1], xr, xi, h[0], am, dc);
                 }
                 if constexpr (V == 2) {
                     const T xr = x[1].x * sc, xi = x[1].y * sc;
-                    ta[2] += xr * h[1].x - xi * h[1].y;
-                    ta[3] += xr * h[1].y + xi * h[1].x;
+                    cmac(ta[2], ta[3], xr, xi, h[1]);
                 }
             }
 #pragma unroll
@@ -534,14 +552,11 @@ mac_xbar_kernel(const MacEntry<T> *__restrict__ entries, const ChunkRange *__res
                 // real*real product per component (fftw_convfuns.h:545-559)
                 {
                     const T xr = x[0].x * sc, xi = x[0].y * sc;
-                    const T hsel = dc ? h[0].y : h[0].x;
-                    acc[j][0] += xr * h[0].x - (am * xi) * h[0].y;
-                    acc[j][1] += (am * xr) * h[0].y + xi * hsel;
+                    cmac_first(acc[j][0], acc[j][1], xr, xi, h[0], am, dc);
                 }
                 if constexpr (V == 2) {
                     const T xr = x[1].x * sc, xi = x[1].y * sc;
-                    acc[j][2] += xr * h[1].x - xi * h[1].y;
-                    acc[j][3] += xr * h[1].y + xi * h[1].x;
+                    cmac(acc[j][2], acc[j][3], xr, xi, h[1]);
                 }
             }
         }
@@ -743,8 +758,8 @@ mac_filter_kernel(const FilterJob<T> *__restrict__ jobs, int L, unsigned int t, 
             c2<T> h;
             if (job.kind == TERM_COEFF) h = job.H[(size_t)p * L + k];
             else { const T f = (T)1.0 / (T)(2 * L); h = mk<T>((k & 1) ? -f : f, (T)0); if (k == 0) h.y = f; }
-            if (k == 0) { acc[0] += x.x * h.x; acc[1] += x.y * h.y; }
-            else { acc[2 * v] += x.x * h.x - x.y * h.y; acc[2 * v + 1] += x.x * h.y + x.y * h.x; }
+            if (k == 0) { acc[0] = fma_t(x.x, h.x, acc[0]); acc[1] = fma_t(x.y, h.y, acc[1]); }
+            else cmac(acc[2 * v], acc[2 * v + 1], x.x, x.y, h);
         }
     }
 #pragma unroll

@@ -224,6 +224,14 @@ int bfhip_engine_rt_stats(const bfhip_engine *e, unsigned long long *graph_block
                           unsigned long long *direct_blocks, unsigned long long *captures);
 
 
+/* The reference skips partitions whose input block does not exist yet (procblocks guard,
+   bfrun.c:1745), so the first n_blocks blocks after start cost less than the steady state.  This
+   call declares the (zero-initialised) rings to hold n_blocks blocks of silence: every block
+   from the first one on does the full work, with the same output (silence contributes
+   nothing).  For measurements; only valid before the first block.  The engine's block counter
+   starts at its ring depth instead of 0 afterwards. */
+int bfhip_engine_prewarm(bfhip_engine *e);
+
 /* Several engines that make up one filter (the segments of include/bfhip_nupc.h) can report into
    one status word in device memory: the NaN/Inf and safety-limit bits (real2raw.h:24-41) are
    OR-ed into *status_dev instead of the engine's own word, and reading / clearing it is the

@@ -469,3 +469,20 @@ def test_subsample_delay_inputs_and_outputs(hip, rs):
         assert gs == os_ == 0
         gsamp, osamp = cases.samples(g, ofmt), cases.samples(o, ofmt)
         assert cases.rel_rms(gsamp, osamp) <= tol, (b, cases.rel_rms(gsamp, osamp))
+
+
+def test_prewarm_changes_cost_not_results(hip):
+    """bfhip_engine_prewarm: rings declared full of silence; outputs identical to a cold start,
+    including for a ring depth that is not a power of two (unsigned wrap of blockcounter - p)"""
+    L, N, I, O = 128, 13, 2, 3
+    coeffs = [(_ir(90 + k, L * N, I), 1.0, 0) for k in range(I * O)]
+    filters = [dict(in_ch=[i], out_ch=[o], coeff=o * I + i, delayblocks=(o + 2 * i) % 5) for o in range(O) for i in range(I)]
+    spec = _spec(L, N, 4, I, O, filters, coeffs, outfmt="S32_LE")
+    a, b = cases.build(hip.Engine, spec), cases.build(hip.Engine, spec)
+    b.prewarm()
+    for k, blk in enumerate(cases.raw_blocks(4, 2 * N + 3, L, I, spec["infmt"])):
+        sa, ra = a.block(blk)
+        sb, rb = b.block(blk)
+        assert sa == sb and np.array_equal(ra, rb), k
+    with pytest.raises(hip.BfhipError, match="already"):
+        b.prewarm()
