@@ -253,7 +253,8 @@ struct bfhip_engine {
     int n_groups = 0, n_out_padded = 0, n_chunks = 1, n_tiles = 1, mac_threads = 256;
     int n_entries = 0;
     bool mac_nt = true;            // non-temporal coefficient loads (BFHIP_MAC_NT=0 turns them off)
-    int mac_unroll = 3;            // partitions in flight per wave (BFHIP_MAC_UNROLL=1..4, tools/tune_mac.py)
+    int mac_unroll = 0;            // 0: rotating three-stage pipeline; 1..4: plain unroll (BFHIP_MAC_UNROLL, tools/tune_mac.py)
+    bool all_dense = false;        // every MAC entry takes the crossbar path
     double alg_bytes_total = 0, alg_bytes_mac = 0;
 
     // real-time mode (bfhip_engine_rt_*): pinned host double buffer, the block's launch
@@ -404,6 +405,10 @@ void launch_mac(bfhip_engine *e, void *Zp, hipError_t *err) {
                        (c2<T> *)Zp, e->L, e->n_out_padded, e->n_groups, e->n_chunks, n_tc,               \
                        e->blockcounter, (int)age64, (const BlockState *)e->bs_arg)
     if (!e->mac_nt) BFHIP_LAUNCH_MAC(false, 2);
+    // the pipelined variant needs ~290 VGPRs: worth it for the pure crossbar, a loss of occupancy
+    // for plans that (also) run the latency-bound per-term paths
+    else if (e->mac_unroll == 0 && e->all_dense) BFHIP_LAUNCH_MAC(true, 0);
+    else if (e->mac_unroll == 0) BFHIP_LAUNCH_MAC(true, 2);
     else if (e->mac_unroll == 4) BFHIP_LAUNCH_MAC(true, 4);
     else if (e->mac_unroll == 3) BFHIP_LAUNCH_MAC(true, 3);
     else if (e->mac_unroll == 1) BFHIP_LAUNCH_MAC(true, 1);
@@ -660,6 +665,7 @@ int build_plan_t(bfhip_engine *e) {
     S = std::max(1, std::min<int>(S, (int)max_entries));
     e->n_chunks = S;
 
+    e->all_dense = true;
     for (auto &v : per_group) {
         for (auto &en : v) {
             bool dense = en.maxP > en.p0;
@@ -667,6 +673,7 @@ int build_plan_t(bfhip_engine *e) {
             en.dense = dense ? 1 : 0;
             // exactly one coefficient term (one-to-one filters, massive_config style): its own
             // pipelined path, 2 + index of the term
+            if (en.dense != 1) e->all_dense = false;
             int n_active = 0, only = -1;
             for (int q = 0; q < OG; q++) if (en.term[q].kind != TERM_NONE) { n_active++; only = q; }
             if (!dense && n_active == 1 && en.term[only].kind == TERM_COEFF && en.maxP > en.p0) en.dense = 2 + only;

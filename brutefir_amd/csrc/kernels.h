@@ -450,7 +450,54 @@ mac_xbar_kernel(const MacEntry<T> *__restrict__ entries, const ChunkRange *__res
             T sc[OG];
 #pragma unroll
             for (int j = 0; j < OG; j++) { Hs[j] = E->term[j].H; sc[j] = E->term[j].scale; }
-#pragma unroll UNROLL
+            constexpr int UR = UNROLL > 0 ? UNROLL : 1;
+            if constexpr (UNROLL == 0) {
+                // Rotating three-stage pipeline: while one partition's products are accumulated
+                // the loads of the next two are in flight and the one after is being issued --
+                // the memory pipe never drains inside an entry.
+                struct Stage { c2<T> x[V]; c2<T> h[OG][V]; };
+                auto issue = [&](Stage &st, int p) {
+                    const unsigned int slot = (t - (unsigned int)p - (unsigned int)delay) % (unsigned int)R;
+                    const unsigned int xoff = (slot * (unsigned int)L + (unsigned int)k0) * (unsigned int)sizeof(c2<T>);
+                    const unsigned int hoff = ((unsigned int)p * (unsigned int)L + (unsigned int)k0) * (unsigned int)sizeof(c2<T>);
+                    Load16<T, false>::get((const c2<T> *)((const char *)ring + xoff), st.x);
+#pragma unroll
+                    for (int j = 0; j < OG; j++) Load16<T, NT>::get((const c2<T> *)((const char *)Hs[j] + hoff), st.h[j]);
+                };
+                auto consume = [&](const Stage &st) {
+#pragma unroll
+                    for (int j = 0; j < OG; j++) {
+                        {
+                            const T xr = st.x[0].x * sc[j], xi = st.x[0].y * sc[j];
+                            cmac_first(acc[j][0], acc[j][1], xr, xi, st.h[j][0], am, dc);
+                        }
+                        if constexpr (V == 2) {
+                            const T xr = st.x[1].x * sc[j], xi = st.x[1].y * sc[j];
+                            cmac(acc[j][2], acc[j][3], xr, xi, st.h[j][1]);
+                        }
+                    }
+                };
+                const int n = maxP - p0;
+                Stage s0, s1, s2;
+                if (n >= 1) issue(s0, p0);
+                if (n >= 2) issue(s1, p0 + 1);
+                if (n >= 3) issue(s2, p0 + 2);
+                int i = 0;
+                for (; i + 6 <= n; i += 3) {                 // steady state: no conditions
+                    consume(s0); issue(s0, p0 + i + 3);
+                    consume(s1); issue(s1, p0 + i + 4);
+                    consume(s2); issue(s2, p0 + i + 5);
+                }
+                for (; i + 3 <= n; i += 3) {                 // at most two trips
+                    consume(s0); if (i + 3 < n) issue(s0, p0 + i + 3);
+                    consume(s1); if (i + 4 < n) issue(s1, p0 + i + 4);
+                    consume(s2); if (i + 5 < n) issue(s2, p0 + i + 5);
+                }
+                if (i < n) consume(s0);
+                if (i + 1 < n) consume(s1);
+                continue;
+            }
+#pragma unroll UR
             for (int p = p0; p < maxP; p++) {
                 // byte offsets kept in 32 bits (N * L * 16 < 4 GiB) so that the loads take the
                 // scalar-base + 32-bit lane-offset form

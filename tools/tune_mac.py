@@ -18,23 +18,28 @@ import brutefir_amd as bf  # noqa: E402
 
 
 def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    rounds = 3
-    if "--rounds" in sys.argv:
-        rounds = int(sys.argv[sys.argv.index("--rounds") + 1])
-        args = [a for a in args if a != str(rounds)] or args
-    knob = "BFHIP_MAC_TARGET_WGS"
-    if "--env" in sys.argv:
-        knob = sys.argv[sys.argv.index("--env") + 1]
-        args = [a for a in args if a != knob]
-    grid = "--grid" in sys.argv
-    cands = ([a for a in args if ":" in a] if grid else [int(a) for a in args]) or [512, 1024, 2048]
-    I, O, L, N, rs, fmt = bench.WORKLOADS["C"]
+    argv = sys.argv[1:]
+
+    def opt(name, default=None):
+        if name in argv:
+            i = argv.index(name)
+            v = argv[i + 1]
+            del argv[i:i + 2]
+            return v
+        return default
+    rounds = int(opt("--rounds", 3))
+    knob = opt("--env", "BFHIP_MAC_TARGET_WGS")
+    wl = opt("--workload", "C")
+    grid = "--grid" in argv
+    if grid:
+        argv.remove("--grid")
+    cands = (list(argv) if grid else [int(a) for a in argv]) or [512, 1024, 2048]
+    I, O, L, N, rs, fmt = bench.WORKLOADS[wl]
     dev = torch.device("cuda", 0)
     eng = bf.Engine(L, N, rs, I, O)
     eng.set_interleaved(bf.IN, fmt)
     eng.set_interleaved(bf.OUT, fmt)
-    h = bench.synth_ir_dev(torch, 1, L * N, I, dev)
+    h = bench.synth_ir_dev(torch, 1, L * N, I, dev).to(torch.float32 if rs == 4 else torch.float64)
     for o in range(O):
         for i in range(I):
             eng.add_filter(in_ch=[i], out_ch=[o], coeff=eng.add_coeff_dev(h, L * N))
@@ -42,6 +47,9 @@ def main():
     eng.finalize()
     raw_in = bench.synth_raw_blocks(torch, 2, L, I, dev)
     raw_out = torch.zeros(L, O, dtype=torch.int32, device=dev)
+    if fmt != "S24_4LE":
+        raw_in = (torch.randn(2, L, I, device=dev, dtype=torch.float64) * 0.1).contiguous()
+        raw_out = torch.zeros(L, O, dtype=torch.float64, device=dev)
     for k in range(N + 2):
         eng.block_dev(raw_in[k % 2], raw_out)
     eng.sync()
