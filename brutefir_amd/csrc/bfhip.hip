@@ -282,6 +282,8 @@ struct bfhip_engine {
     bool timing = false;
     std::vector<hipEvent_t> ev;    // 6 per block: start/stop of K1, K2, K3 on their streams
     int ev_used = 0;
+    int timing_stride = 1;         // time every n-th block (the event records cost ~3 us each)
+    bool timed_now = false;
 
     size_t csize() const { return (size_t)2 * rs; }     // bytes per complex
 };
@@ -829,7 +831,7 @@ int check_format(const bfhip_format *f) {
 }
 
 int record(bfhip_engine *e, int idx) {
-    if (!e->timing || e->ev_used >= MAX_TIMED) return BFHIP_OK;
+    if (!e->timed_now) return BFHIP_OK;
     HIPCHK(hipEventRecord(e->ev[(size_t)e->ev_used * 6 + idx], e->ls));
     return BFHIP_OK;
 }
@@ -1831,6 +1833,7 @@ int bfhip_engine_block_dev(bfhip_engine *e, const void *rawin_dev, void *rawout_
     const bool pipe = e->pipelined;
     const int buf = (int)(e->blocks_done & 1);
     void *Zp = (pipe && buf) ? e->d_Zp2 : e->d_Zp;
+    e->timed_now = e->timing && e->ev_used < MAX_TIMED && e->blocks_done % (unsigned long long)e->timing_stride == 0;
 
     // K1 on the input stream.  It overwrites the ring slot of block t-R, last read by the MAC
     // of block t-2 (the MAC of t-1 reaches back only N = R-1 blocks).
@@ -1862,7 +1865,8 @@ int bfhip_engine_block_dev(bfhip_engine *e, const void *rawin_dev, void *rawout_
     if ((r = record(e, 5)) != BFHIP_OK) return r;
     if (pipe) HIPCHK(hipEventRecord(e->ev_out[buf], e->s_out));
     e->ls = e->stream;
-    if (e->timing && e->ev_used < MAX_TIMED) e->ev_used++;
+    if (e->timed_now) e->ev_used++;
+    e->timed_now = false;
     advance(e);
     return BFHIP_OK;
 }
@@ -2073,6 +2077,7 @@ int bfhip_engine_enable_timing(bfhip_engine *e, int on) {
     }
     { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
     e->timing = on != 0;
+    e->timing_stride = on > 1 ? on : 1;
     e->ev_used = 0;
     return BFHIP_OK;
 }

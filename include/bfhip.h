@@ -254,7 +254,8 @@ int bfhip_engine_ring_depth(const bfhip_engine *e);
 
 /* HIP-event timing of the three kernels of a block on the engine's stream.  ms[0..2] =
    mean duration of the input-FFT, MAC and output-IFFT launches since the last reset,
-   ms[3] = launches averaged.  Reading synchronises the stream. */
+   ms[3] = launches averaged.  Reading synchronises the stream.  on = n > 1 times every n-th
+   block only (six event records per timed block cost the stream ~20 us). */
 int bfhip_engine_enable_timing(bfhip_engine *e, int on);
 int bfhip_engine_get_timing(bfhip_engine *e, double ms[4]);
 /* algorithmic bytes of one block per SURVEY 8(d): bytes[0] total, [1] MAC kernel only
