@@ -54,6 +54,27 @@ def test_argument_validation_needs_no_device():
     assert b"Invalid real size" in L.bfhip_last_error()
 
 
+def test_nonuniform_schedule_validation_needs_no_device():
+    """bfhip_nupc_create rejects a schedule whose long partitions could not be ready in time
+    before it touches the device (include/bfhip_nupc.h)"""
+    import brutefir_amd as bf
+    with pytest.raises(bf.BfhipError, match="not be ready in time"):
+        bf.Nupc([64, 1024], [2, 4], 4, 1, 1)
+    with pytest.raises(bf.BfhipError, match="ascend"):
+        bf.Nupc([128, 64], [2, 2], 4, 1, 1)
+    if bf.device_count() == 0:
+        with pytest.raises(bf.BfhipError, match="no HIP device"):
+            bf.Nupc([64, 128], [2, 2], 4, 1, 1)
+
+
+def test_realtime_entry_points_need_a_finalized_engine():
+    import brutefir_amd as bf
+    L = bf.lib()
+    assert L.bfhip_engine_rt_submit(None, None) < 0
+    assert b"not in real-time mode" in L.bfhip_last_error()
+    assert L.bfhip_engine_rt_buffer(None, 0, 0) is None
+
+
 def test_product_never_imports_the_oracle():
     for path in glob.glob(os.path.join(ROOT, "brutefir_amd", "**", "*"), recursive=True):
         if os.path.isfile(path) and path.endswith((".py", ".h", ".hip", ".cpp", ".c")):
