@@ -66,3 +66,22 @@ def test_c_host_realtime_round_trip(hip):
     for ln in lines:
         assert ln["outputs_identical"] is True, ln
         assert ln["rt_spin"][0] <= ln["block"][0] * 1.1, ln
+
+
+def test_c_host_with_rccl_reduce_scatter(hip):
+    """examples/bfmulti.c: the sharded block (inputs -> partial spectra -> ncclReduceScatter ->
+    outputs) driven from plain C with RCCL's C API.  On this one-GPU box the communicator has a
+    single rank, so the collective is a copy and the result must equal the fused block call
+    byte for byte; with more GPUs the same binary shards the inputs over all of them."""
+    import json
+    exe = os.path.join(ROOT, "examples", "bfmulti")
+    subprocess.check_call(["gcc", "-O2", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "bfmulti.c"),
+                           "-o", exe, "-L" + os.path.join(ROOT, "brutefir_amd"), "-lbfhip",
+                           "-L/opt/rocm/lib", "-lamdhip64", "-lrccl", "-lm",
+                           "-Wl,-rpath," + os.path.join(ROOT, "brutefir_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    r = subprocess.run([exe, "1", "12", "8", "8", "1024", "6"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["status_bits"] == 0
+    assert line["max_abs_output"] > 1000 and line["max_abs_difference_vs_block_dev"] == 0
