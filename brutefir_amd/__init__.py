@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libbfhip.so")
 
 IN, OUT = 0, 1
-RT_SPIN, RT_NO_GRAPH = 1, 2      # bfhip_engine_rt_begin flags
+RT_SPIN, RT_NO_GRAPH, RT_COPY_ENGINE, RT_OVERLAP = 1, 2, 4, 8      # bfhip_engine_rt_begin flags
 ST_NONFINITE, ST_SAFETY = 1, 2
 
 

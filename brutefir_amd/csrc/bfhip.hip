@@ -273,6 +273,10 @@ struct bfhip_engine {
         unsigned int bs_t = 0;                      // what d_bs->t holds
         bool bs_synced = false;
         unsigned long long n_graph = 0, n_direct = 0, n_capture = 0;
+        // BFHIP_RT_OVERLAP: copies of neighbouring periods run on the copy engines beside compute
+        hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+        hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_cmp[2] = {nullptr, nullptr};
+        uint8_t *d_in[2] = {nullptr, nullptr}, *d_out[2] = {nullptr, nullptr};
     } rt;
     BlockState *d_bs = nullptr;
     unsigned int *d_rt_arrive = nullptr;
@@ -1023,7 +1027,13 @@ void rt_release(bfhip_engine *e) {
         if (rt.h_out[p]) (void)hipHostFree(rt.h_out[p]);
         if (rt.h_over[p]) (void)hipHostFree(rt.h_over[p]);
         if (rt.h_status[p]) (void)hipHostFree(rt.h_status[p]);
+        if (rt.ev_h2d[p]) (void)hipEventDestroy(rt.ev_h2d[p]);
+        if (rt.ev_cmp[p]) (void)hipEventDestroy(rt.ev_cmp[p]);
+        if (rt.d_in[p]) (void)hipFree(rt.d_in[p]);
+        if (rt.d_out[p]) (void)hipFree(rt.d_out[p]);
     }
+    if (rt.s_h2d) (void)hipStreamDestroy(rt.s_h2d);
+    if (rt.s_d2h) (void)hipStreamDestroy(rt.s_d2h);
     if (e->d_bs) (void)hipFree(e->d_bs);
     if (e->d_rt_arrive) (void)hipFree(e->d_rt_arrive);
     e->d_bs = nullptr;
@@ -1033,15 +1043,43 @@ void rt_release(bfhip_engine *e) {
 
 // can this plan's launch sequence be replayed unchanged block after block?
 bool rt_graphable(const bfhip_engine *e) {
-    if (e->rt.flags & BFHIP_RT_NO_GRAPH) return false;
+    if (e->rt.flags & (BFHIP_RT_NO_GRAPH | BFHIP_RT_OVERLAP)) return false;
     // N:1 channels and sub-sample delays upload a per-block job table; a cross-fade lasts one block
     return !e->has_vchan && !side_uses_subdelay(e, 0) && !side_uses_subdelay(e, 1) && !e->any_fading;
+}
+
+// Throughput with host buffers: upload of period t+1 and download of period t-1 on the copy
+// engines (their own streams) while period t computes -- the reference's input / filter / output
+// process pipeline over its two buffer halves (bfrun.c:2031, 2312-2616).  Two periods must be
+// in flight for the overlap to happen (rt_submit before rt_wait of the previous one).
+int rt_enqueue_overlap(bfhip_engine *e, int p) {
+    auto &rt = e->rt;
+    int r;
+    HIPCHK(hipMemcpyAsync(rt.d_in[p], rt.h_in[p], e->raw_bytes[0], hipMemcpyHostToDevice, rt.s_h2d));
+    HIPCHK(hipEventRecord(rt.ev_h2d[p], rt.s_h2d));
+    e->ls = e->stream;
+    HIPCHK(hipStreamWaitEvent(e->stream, rt.ev_h2d[p], 0));
+    if ((r = do_inputs(e, rt.d_in[p])) != BFHIP_OK) return r;
+    if ((r = do_levels(e)) != BFHIP_OK) return r;
+    if ((r = do_mac(e, e->d_Zp)) != BFHIP_OK) return r;
+    if ((r = do_outputs(e, e->d_Zp, (size_t)e->n_out_padded * e->L, e->n_chunks, 0, e->n_ch[1], rt.d_out[p])) != BFHIP_OK) return r;
+    RtCopy none;
+    none.dst = nullptr; none.src = nullptr; none.n16 = 0; none.pad = 0;
+    hipLaunchKernelGGL(rt_tail_kernel<0>, dim3(1), dim3(256), 0, e->stream, none, e->d_bs, e->N,
+                       (const DevOverflow *)e->d_over, rt.h_over[p], e->n_ch[1], e->d_status, rt.h_status[p], e->d_rt_arrive);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(rt.ev_cmp[p], e->stream));
+    HIPCHK(hipStreamWaitEvent(rt.s_d2h, rt.ev_cmp[p], 0));
+    HIPCHK(hipMemcpyAsync(rt.h_out[p], rt.d_out[p], e->raw_bytes[1], hipMemcpyDeviceToHost, rt.s_d2h));
+    HIPCHK(hipEventRecord(rt.done[p], rt.s_d2h));
+    return BFHIP_OK;
 }
 
 // the launch sequence of one block on the main stream: pinned in -> device -> pinned out
 int rt_enqueue(bfhip_engine *e, int p) {
     auto &rt = e->rt;
     int r;
+    if (rt.flags & BFHIP_RT_OVERLAP) return rt_enqueue_overlap(e, p);
     e->ls = e->stream;
     const bool nodes = (rt.flags & BFHIP_RT_COPY_ENGINE) != 0;
     RtCopy cin, cout;
@@ -1913,6 +1951,17 @@ int bfhip_engine_rt_begin(bfhip_engine *e, int flags) {
         memset(rt.h_over[p], 0, e->n_ch[1] * sizeof(DevOverflow));
         rt.h_status[p][0] = rt.h_status[p][1] = 0;
         HIPCHK(hipEventCreateWithFlags(&rt.done[p], hipEventDisableTiming));
+        if (flags & BFHIP_RT_OVERLAP) {
+            HIPCHK(hipEventCreateWithFlags(&rt.ev_h2d[p], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&rt.ev_cmp[p], hipEventDisableTiming));
+            HIPCHK(hipMalloc((void **)&rt.d_in[p], e->raw_bytes[0] + 16));
+            HIPCHK(hipMalloc((void **)&rt.d_out[p], e->raw_bytes[1] + 16));
+            HIPCHK(hipMemset(rt.d_out[p], 0, e->raw_bytes[1] + 16));
+        }
+    }
+    if (flags & BFHIP_RT_OVERLAP) {
+        HIPCHK(hipStreamCreateWithFlags(&rt.s_h2d, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&rt.s_d2h, hipStreamNonBlocking));
     }
     HIPCHK(hipMalloc((void **)&e->d_bs, sizeof(BlockState)));
     HIPCHK(hipMalloc((void **)&e->d_rt_arrive, sizeof(unsigned int)));
@@ -1966,7 +2015,7 @@ int bfhip_engine_rt_submit(bfhip_engine *e, const void *rawin) {
         rt.primed = true;
         rt.n_direct++;
     }
-    HIPCHK(hipEventRecord(rt.done[p], e->stream));
+    if (!(rt.flags & BFHIP_RT_OVERLAP)) HIPCHK(hipEventRecord(rt.done[p], e->stream));   // else: after the download
     rt.submitted++;
     advance(e);
     rt.bs_t = e->blockcounter;
@@ -1979,7 +2028,7 @@ int bfhip_engine_rt_wait(bfhip_engine *e, void *rawout, bfhip_overflow overflow[
     if (rt.submitted == rt.waited) return fail(BFHIP_ESTATE, "rt_wait: nothing in flight");
     const int p = (int)(rt.waited & 1);
     HIPCHK(hipSetDevice(e->device));
-    if (rt.flags & BFHIP_RT_SPIN) {
+    if ((rt.flags & BFHIP_RT_SPIN) && !(rt.flags & BFHIP_RT_OVERLAP)) {
         // the tail kernel's last store is the sequence word: watch it from the CPU, fall back to
         // the runtime after ~2 ms so that a device error cannot hang the caller
         volatile int *seq = rt.h_status[p] + 1;

@@ -207,6 +207,9 @@ int bfhip_engine_advance(bfhip_engine *e);
 #define BFHIP_RT_SPIN     1   /* wait by watching the pinned completion word (lowest latency, burns the core) */
 #define BFHIP_RT_NO_GRAPH 2   /* never replay: plain launches from the pinned buffers */
 #define BFHIP_RT_COPY_ENGINE 4 /* stage the period with memcpy nodes instead of copy kernels */
+#define BFHIP_RT_OVERLAP  8   /* throughput with host buffers: upload of period t+1 and download of
+                                 period t-1 ride the copy engines while period t computes (no graph
+                                 replay); keep two periods in flight with rt_submit / rt_wait */
 int bfhip_engine_rt_begin(bfhip_engine *e, int flags);
 int bfhip_engine_rt_end(bfhip_engine *e);
 /* the pinned buffers (io 0 = in, 1 = out; index 0/1): period k uses index k & 1.  A host that

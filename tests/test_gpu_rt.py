@@ -66,6 +66,10 @@ def test_two_periods_in_flight(hip):
     filters = [dict(in_ch=[i], out_ch=[o], coeff=o * I + i) for o in range(O) for i in range(I)]
     st = _twin(hip, _spec(L, N, 4, I, O, filters, coeffs, outfmt="S32_LE"), 20, pattern="pipelined")
     assert st["graph"] == 19
+    # BFHIP_RT_OVERLAP: copies on their own streams beside compute; same bytes out
+    for pattern in ("pipelined", "block"):
+        st = _twin(hip, _spec(L, N, 4, I, O, filters, coeffs, outfmt="S32_LE"), 20, flags=hip.RT_OVERLAP, pattern=pattern)
+        assert st["graph"] == 0 and st["direct"] == 20
     e = cases.build(hip.Engine, _spec(L, N, 4, I, O, filters, coeffs))
     e.rt_begin()
     blk = cases.raw_blocks(1, 1, L, I, "S24_4LE")[0]
