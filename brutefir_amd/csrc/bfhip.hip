@@ -20,6 +20,9 @@
 #include <map>
 #include <string>
 #include <vector>
+#include <mutex>
+#include <set>
+#include <tuple>
 
 #include "../../include/bfhip.h"
 #include "kernels.h"
@@ -322,9 +325,20 @@ int sync_all(bfhip_engine *e) {
         else { DISPATCH_LOG2L(double, FN, __VA_ARGS__) }                    \
     } while (0)
 
+// raise a kernel's dynamic-LDS limit once per (device, kernel, size): the attribute call costs a
+// few microseconds, which is real money in a 35 us block
 template <typename K> hipError_t allow_lds(K kernel, size_t bytes) {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    static std::mutex mu;
+    static std::set<std::tuple<int, const void *, size_t>> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const auto key = std::make_tuple(dev, reinterpret_cast<const void *>(kernel), bytes);
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count(key)) return hipSuccess;
+    const hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (r == hipSuccess) done.insert(key);
+    return r;
 }
 
 template <typename T, int LOG2L>
