@@ -33,6 +33,8 @@ WORKLOADS = {
     # what ONE rank of an N-GPU run of config C computes (inputs sharded, all outputs)
     "C2": (32, 64, 8192, 32, 4, "S24_4LE"), "C4": (16, 64, 8192, 32, 4, "S24_4LE"),
     "C8": (8, 64, 8192, 32, 4, "S24_4LE"),
+    # a float64 crossbar of the headline's byte volume per filter (informative: the f64 MAC path)
+    "F": (32, 32, 8192, 32, 8, "FLOAT64_LE"),
 }
 DIAGONAL = {"D"}
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec

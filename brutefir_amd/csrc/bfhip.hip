@@ -697,6 +697,18 @@ int build_plan_t(bfhip_engine *e) {
             int n_active = 0, only = -1;
             for (int q = 0; q < OG; q++) if (en.term[q].kind != TERM_NONE) { n_active++; only = q; }
             if (!dense && n_active == 1 && en.term[only].kind == TERM_COEFF && en.maxP > en.p0) en.dense = 2 + only;
+            // several (not all OG) coefficient terms of full length: the crossbar path over a subset
+            en.mask = 0;
+            if (!dense && n_active >= 2 && en.maxP > en.p0) {
+                bool ok = true;
+                int mask = 0;
+                for (int q = 0; q < OG; q++) {
+                    if (en.term[q].kind == TERM_NONE) continue;
+                    ok = ok && en.term[q].kind == TERM_COEFF && en.term[q].P >= en.maxP;
+                    mask |= 1 << q;
+                }
+                if (ok) { en.dense = 16; en.mask = mask; }
+            }
         }
     }
 

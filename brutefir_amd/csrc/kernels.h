@@ -53,7 +53,10 @@ template <typename T> struct MacEntry {
     int delay;          // filter delay in blocks (bfrun.c:1579-1584)
     int p0;             // first partition this entry covers (entries may be split along p)
     int maxP;           // one past the last partition: max over terms of P, or the split point
-    int dense;          // all OG terms are coefficient terms with P == maxP: pipelined path
+    int dense;          // 1: all OG terms are coefficient terms with P >= maxP (crossbar path);
+                        // 16: the same for the subset `mask` of the terms, the rest empty;
+                        // 2 + j: term j is the only one; 0: generic per-term path
+    int mask;           // dense == 16: bit j set = term j is active
     MacTerm<T> term[OG];
 };
 
@@ -442,15 +445,44 @@ mac_xbar_kernel(const MacEntry<T> *__restrict__ entries, const ChunkRange *__res
         const int p0 = E->p0;
         int maxP = E->maxP;
         if (maxP > age - delay) maxP = age - delay;     // blocks that exist yet (procblocks)
-        if (E->dense == 1) {
-            // The crossbar case: OG coefficient terms of equal length.  Per partition one ring
+        if (E->dense == 1 || E->dense == 16) {
+            const unsigned int mask = E->dense == 1 ? 0xffu : (unsigned int)E->mask;
+            // The crossbar case: OG coefficient terms of equal length (or, for the last group of
+            // a crossbar whose output count is not a multiple of OG and for small matrices, the
+            // `mask` subset of them: wave-uniform branches around the absent ones).  Per partition one ring
             // load and OG coefficient loads (1 KiB per wave each) are issued back to back from
             // wave-uniform bases + one shared lane offset, then accumulated as they land.
             const c2<T> *Hs[OG];
             T sc[OG];
 #pragma unroll
             for (int j = 0; j < OG; j++) { Hs[j] = E->term[j].H; sc[j] = E->term[j].scale; }
-            constexpr int UR = UNROLL > 0 ? UNROLL : 1;
+            constexpr int UR = UNROLL > 0 ? UNROLL : 2;
+            if (mask != 0xffu) {
+#pragma unroll 2
+                for (int p = p0; p < maxP; p++) {
+                    const unsigned int slot = (t - (unsigned int)p - (unsigned int)delay) % (unsigned int)R;
+                    const unsigned int xoff = (slot * (unsigned int)L + (unsigned int)k0) * (unsigned int)sizeof(c2<T>);
+                    const unsigned int hoff = ((unsigned int)p * (unsigned int)L + (unsigned int)k0) * (unsigned int)sizeof(c2<T>);
+                    c2<T> x[V], h[OG][V];
+                    Load16<T, false>::get((const c2<T> *)((const char *)ring + xoff), x);
+#pragma unroll
+                    for (int j = 0; j < OG; j++)
+                        if (mask & (1u << j)) Load16<T, NT>::get((const c2<T> *)((const char *)Hs[j] + hoff), h[j]);
+#pragma unroll
+                    for (int j = 0; j < OG; j++) {
+                        if (!(mask & (1u << j))) continue;
+                        {
+                            const T xr = x[0].x * sc[j], xi = x[0].y * sc[j];
+                            cmac_first(acc[j][0], acc[j][1], xr, xi, h[j][0], am, dc);
+                        }
+                        if constexpr (V == 2) {
+                            const T xr = x[1].x * sc[j], xi = x[1].y * sc[j];
+                            cmac(acc[j][2], acc[j][3], xr, xi, h[j][1]);
+                        }
+                    }
+                }
+                continue;
+            }
             if constexpr (UNROLL == 0) {
                 // Rotating three-stage pipeline: while one partition's products are accumulated
                 // the loads of the next two are in flight and the one after is being issued --
@@ -522,7 +554,7 @@ mac_xbar_kernel(const MacEntry<T> *__restrict__ entries, const ChunkRange *__res
             }
             continue;
         }
-        if (E->dense >= 2) {
+        if (E->dense >= 2 && E->dense < 2 + OG) {
             // One coefficient term only (one-to-one filters): nothing to reuse, so the depth
             // comes from four partitions (ring + coefficient tile each) in flight per wave.
             const int js = E->dense - 2;
