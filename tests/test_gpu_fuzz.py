@@ -1,0 +1,110 @@
+"""GPU: randomly generated filter networks and run-time control sequences, HIP engine vs oracle.
+
+Every bookkeeping rule of the path interacts with every other one in the plan builder (shared
+vs private rings, cascade levels, promotion on scale/delay changes, one-block cross-fades,
+dirac terms, short coefficient sets, delay clamping, partial output groups ...).  The
+hand-written feature tests cover the rules one or two at a time; this one draws whole
+configurations: random topology (channel inputs, filter inputs from earlier filters, several
+outputs per filter, outputs fed by several filters, unused outputs), random scales incl.
+negative and zero, random `coeff` incl. -1, random delayblocks incl. beyond N-1, random
+crossfade flags, and a random schedule of `fctrl` writes (coeff / scale / fscale / delayblocks)
+between blocks.  Same seeded input blocks into both engines; float outputs compared block by
+block (f32 3e-5 / f64 1e-11 relative RMS -- cascades go through several FFT round trips),
+status bits and overflow counters equal."""
+import numpy as np
+import pytest
+
+import bforacle as bo
+import cases
+
+pytestmark = pytest.mark.gpu
+FLOATFMT = {4: "FLOAT_LE", 8: "FLOAT64_LE"}
+
+
+def _network(seed):
+    rng = np.random.default_rng(1000 + seed)
+    L = int(rng.choice([64, 128, 256]))
+    N = int(rng.integers(1, 10))
+    rs = int(rng.choice([4, 8]))
+    n_in, n_out = int(rng.integers(1, 5)), int(rng.integers(1, 12))
+    n_coeffs = int(rng.integers(1, 5))
+    coeffs = []
+    for c in range(n_coeffs):
+        nb = int(rng.integers(1, N + 1))
+        taps = int(rng.integers(1, L * nb + 1)) if rng.random() < 0.3 else L * nb
+        coeffs.append((cases.make_ir(rng, taps, 2), float(rng.choice([1.0, 0.5, -1.0])), nb if rng.random() < 0.5 else 0))
+    n_filters = int(rng.integers(1, 9))
+    filters = []
+    for f in range(n_filters):
+        in_ch = list(rng.choice(n_in, size=int(rng.integers(0, min(3, n_in) + 1)), replace=False))
+        in_f = list(rng.choice(f, size=int(rng.integers(0, min(2, f) + 1)), replace=False)) if f > 0 and rng.random() < 0.4 else []
+        if not in_ch and not in_f:
+            in_ch = [int(rng.integers(0, n_in))]
+        out_ch = list(rng.choice(n_out, size=int(rng.integers(0, min(3, n_out) + 1)), replace=False))
+        sc = lambda k: [float(rng.choice([1.0, -1.0, 0.5, 0.25, 0.0, 1.5])) for _ in range(k)]      # noqa: E731
+        filters.append(dict(in_ch=[int(x) for x in in_ch], in_scale=sc(len(in_ch)),
+                            in_f=[int(x) for x in in_f], in_fscale=sc(len(in_f)),
+                            out_ch=[int(x) for x in out_ch], out_scale=sc(len(out_ch)),
+                            coeff=int(rng.integers(-1, n_coeffs)), delayblocks=int(rng.integers(0, N + 2)),
+                            crossfade=bool(rng.random() < 0.5)))
+    spec = dict(L=L, N=N, rs=rs, n_in=n_in, n_out=n_out, infmt=str(rng.choice(["S16_LE", "S24_4LE", "FLOAT_LE"])),
+                outfmt=FLOATFMT[rs], coeffs=coeffs, filters=filters)
+    n_blocks = 2 * N + 6
+    events = {}
+    for _ in range(int(rng.integers(0, 10))):
+        b = int(rng.integers(1, n_blocks))
+        f = int(rng.integers(0, n_filters))
+        kind = str(rng.choice(["coeff", "scale_in", "scale_out", "fscale", "delay"]))
+        flt = filters[f]
+        if kind == "coeff":
+            ev = ("coeff", f, int(rng.integers(-1, n_coeffs)))
+        elif kind == "scale_in" and flt["in_ch"]:
+            ev = ("scale", f, 0, int(rng.integers(0, len(flt["in_ch"]))), float(rng.choice([1.0, -0.5, 0.0, 2.0])))
+        elif kind == "scale_out" and flt["out_ch"]:
+            ev = ("scale", f, 1, int(rng.integers(0, len(flt["out_ch"]))), float(rng.choice([1.0, -0.5, 0.0, 2.0])))
+        elif kind == "fscale" and flt["in_f"]:
+            ev = ("fscale", f, int(rng.integers(0, len(flt["in_f"]))), float(rng.choice([1.0, -0.5, 0.0, 2.0])))
+        else:
+            ev = ("delay", f, int(rng.integers(0, N + 2)))
+        events.setdefault(b, []).append(ev)
+    return spec, n_blocks, events
+
+
+def _apply(eng, evs):
+    for ev in evs:
+        if ev[0] == "coeff":
+            eng.set_coeff(ev[1], ev[2])
+        elif ev[0] == "scale":
+            eng.set_scale(ev[1], ev[2], ev[3], ev[4])
+        elif ev[0] == "fscale":
+            eng.set_fscale(ev[1], ev[2], ev[3])
+        else:
+            eng.set_delayblocks(ev[1], ev[2])
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("BFHIP_FUZZ_SEEDS", "100"))))
+def test_random_network_and_control_sequence(hip, seed):
+    spec, n_blocks, events = _network(seed)
+    ge, oe = cases.build(hip.Engine, spec), cases.build(bo.Engine, spec)
+    tol = 3e-5 if spec["rs"] == 4 else 1e-11
+    blocks = cases.raw_blocks(seed, n_blocks, spec["L"], spec["n_in"], spec["infmt"], amplitude=0.2)
+    scale = 0.0
+    for b, blk in enumerate(blocks):
+        _apply(ge, events.get(b, []))
+        _apply(oe, events.get(b, []))
+        gs, g = ge.block(blk)
+        os_, o = oe.block(blk)
+        assert gs == os_, (seed, b)
+        gsamp = cases.samples(g, spec["outfmt"]).reshape(spec["L"], spec["n_out"])
+        osamp = cases.samples(o, spec["outfmt"]).reshape(spec["L"], spec["n_out"])
+        scale = max(scale, float(np.abs(osamp).max()))
+        for ch in range(spec["n_out"]):
+            ref = osamp[:, ch]
+            err = float(np.sqrt(((gsamp[:, ch] - ref) ** 2).mean()))
+            # relative to the channel's own level, with a floor at the network's overall level so
+            # that an output which is (nearly) silent by cancellation is judged in absolute terms
+            lvl = max(float(np.sqrt((ref ** 2).mean())), 1e-3 * scale, 1e-30)
+            assert err <= tol * lvl, (seed, b, ch, err, lvl, spec["filters"], events)
+    for ch in range(spec["n_out"]):
+        g, o = ge.overflow(ch), oe.overflow(ch)
+        assert g.n_overflows == o.n_overflows and g.max == o.max, (seed, ch)
