@@ -19,6 +19,8 @@ import cases
 
 pytestmark = pytest.mark.gpu
 FLOATFMT = {4: "FLOAT_LE", 8: "FLOAT64_LE"}
+FLOOR = 0.1 * 0.2           # a tenth of the input amplitude: the rounding noise of an FFT round trip scales with the
+                            # loudest sample in the 2L window, not with what is left after delays and cancellation
 
 
 def _network(seed):
@@ -101,10 +103,92 @@ def test_random_network_and_control_sequence(hip, seed):
         for ch in range(spec["n_out"]):
             ref = osamp[:, ch]
             err = float(np.sqrt(((gsamp[:, ch] - ref) ** 2).mean()))
-            # relative to the channel's own level, with a floor at the network's overall level so
-            # that an output which is (nearly) silent by cancellation is judged in absolute terms
-            lvl = max(float(np.sqrt((ref ** 2).mean())), 1e-3 * scale, 1e-30)
+            # relative to the channel's own level, with a floor tied to the input level (0.2 of
+            # full scale) so that an output which is (nearly) silent -- by cancellation, or because
+            # the delayed signal has not arrived yet -- is judged in absolute terms
+            lvl = max(float(np.sqrt((ref ** 2).mean())), 1e-3 * scale, FLOOR)
             assert err <= tol * lvl, (seed, b, ch, err, lvl, spec["filters"], events)
     for ch in range(spec["n_out"]):
         g, o = ge.overflow(ch), oe.overflow(ch)
         assert g.n_overflows == o.n_overflows and g.max == o.max, (seed, ch)
+
+
+def _vchan_case(seed):
+    rng = np.random.default_rng(5000 + seed)
+    L = int(rng.choice([64, 128, 256]))
+    N = int(rng.integers(1, 6))
+    rs = int(rng.choice([4, 8]))
+    maps, nv = [], []
+    for io in range(2):
+        n_phys = int(rng.integers(1, 4))
+        v2p = []
+        for p in range(n_phys):
+            v2p += [p] * int(rng.integers(1, 4))
+        maps.append(v2p)
+        nv.append(len(v2p))
+    infmt = str(rng.choice(["S16_LE", "S32_LE", "S24_4LE", "FLOAT_LE"]))
+    maxd = [[int(rng.choice([0, 40, 300, 900, -1])) for _ in range(nv[io])] for io in range(2)]
+    lim = lambda md: 1200 if md < 0 else md        # noqa: E731
+    delay = [[int(rng.integers(0, lim(maxd[io][v]) + 1)) for v in range(nv[io])] for io in range(2)]
+    coeffs = [cases.make_ir(rng, L * N, 2) for _ in range(3)]
+    filters = []
+    for v in range(nv[0]):
+        outs = list(rng.choice(nv[1], size=int(rng.integers(1, min(2, nv[1]) + 1)), replace=False))
+        filters.append(dict(in_ch=[v], out_ch=[int(o) for o in outs], coeff=int(rng.integers(-1, 3)),
+                            out_scale=[float(rng.choice([1.0, -0.5, 0.25])) for _ in outs]))
+    n_blocks = 2 * N + 8
+    events = {}
+    for _ in range(int(rng.integers(0, 12))):
+        b = int(rng.integers(1, n_blocks))
+        io = int(rng.integers(0, 2))
+        v = int(rng.integers(0, nv[io]))
+        if rng.random() < 0.7:
+            events.setdefault(b, []).append(("delay", io, v, int(rng.integers(0, lim(maxd[io][v]) + 1))))
+        else:
+            events.setdefault(b, []).append(("mute", io, v, int(rng.integers(0, 2))))
+    return dict(L=L, N=N, rs=rs, maps=maps, nv=nv, infmt=infmt, maxd=maxd, delay=delay, coeffs=coeffs,
+                filters=filters, n_blocks=n_blocks, events=events)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("BFHIP_FUZZ_SEEDS", "60"))))
+def test_random_channel_mappings_delays_and_mutes(hip, seed):
+    """N:1 virtual -> physical channels with random integer delays (short and long regimes of
+    delay.c, unlimited maxdelay included), run-time delay changes and mutes, both sides"""
+    c = _vchan_case(seed)
+    ofmt = FLOATFMT[c["rs"]]
+
+    def mk(cls):
+        e = cls(c["L"], c["N"], c["rs"], c["nv"][0], c["nv"][1])
+        e.map_channels(0, c["maps"][0])
+        e.map_channels(1, c["maps"][1])
+        e.set_interleaved_phys(0, c["infmt"], max(c["maps"][0]) + 1)
+        e.set_interleaved_phys(1, ofmt, max(c["maps"][1]) + 1)
+        for h in c["coeffs"]:
+            e.add_coeff(h)
+        for io in range(2):
+            for v in range(c["nv"][io]):
+                e.set_delay(io, v, c["delay"][io][v])
+                e.set_maxdelay(io, v, c["maxd"][io][v])
+        for f in c["filters"]:
+            e.add_filter(**f)
+        if hasattr(e, "finalize"):
+            e.finalize()
+        return e
+    ge, oe = mk(hip.Engine), mk(bo.Engine)
+    n_phys_in, n_phys_out = max(c["maps"][0]) + 1, max(c["maps"][1]) + 1
+    tol = 1e-5 if c["rs"] == 4 else 1e-12
+    scale = 0.0
+    for b, blk in enumerate(cases.raw_blocks(seed, c["n_blocks"], c["L"], n_phys_in, c["infmt"], amplitude=0.2)):
+        for eng in (ge, oe):
+            for kind, io, v, val in c["events"].get(b, []):
+                (eng.set_delay if kind == "delay" else eng.set_mute)(io, v, val)
+        gs, g = ge.block(blk)
+        os_, o = oe.block(blk)
+        assert gs == os_ == 0, (seed, b)
+        gsamp = cases.samples(g, ofmt).reshape(c["L"], n_phys_out)
+        osamp = cases.samples(o, ofmt).reshape(c["L"], n_phys_out)
+        scale = max(scale, float(np.abs(osamp).max()))
+        for ch in range(n_phys_out):
+            err = float(np.sqrt(((gsamp[:, ch] - osamp[:, ch]) ** 2).mean()))
+            lvl = max(float(np.sqrt((osamp[:, ch] ** 2).mean())), 1e-3 * scale, FLOOR)
+            assert err <= tol * lvl, (seed, b, ch, err, lvl)
