@@ -192,3 +192,71 @@ def test_random_channel_mappings_delays_and_mutes(hip, seed):
             err = float(np.sqrt(((gsamp[:, ch] - osamp[:, ch]) ** 2).mean()))
             lvl = max(float(np.sqrt((osamp[:, ch] ** 2).mean())), 1e-3 * scale, FLOOR)
             assert err <= tol * lvl, (seed, b, ch, err, lvl)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("BFHIP_FUZZ_SEEDS", "40"))))
+def test_random_network_replayed_in_realtime_mode_is_bit_identical(hip, seed):
+    """the same random networks and control sequences through bfhip_engine_rt_block (graph replay,
+    re-capture after every control change, direct launches for fade blocks) and through
+    bfhip_engine_block: identical bytes"""
+    spec, n_blocks, events = _network(seed)
+    spec = dict(spec, outfmt=str(np.random.default_rng(seed).choice(["S16_LE", "S24_4LE", "S32_LE", FLOATFMT[spec["rs"]]])))
+    a, b = cases.build(hip.Engine, spec), cases.build(hip.Engine, spec)
+    b.rt_begin(hip.RT_SPIN if seed & 1 else 0)
+    for k, blk in enumerate(cases.raw_blocks(seed, n_blocks, spec["L"], spec["n_in"], spec["infmt"], amplitude=0.3)):
+        _apply(a, events.get(k, []))
+        _apply(b, events.get(k, []))
+        sa, ra = a.block(blk)
+        sb, rb = b.rt_block(blk)
+        assert sa == sb and np.array_equal(ra, rb), (seed, k)
+    for ch in range(spec["n_out"]):
+        assert a.overflow(ch).astuple() == b.overflow(ch).astuple(), (seed, ch)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("BFHIP_FUZZ_SEEDS", "30"))))
+def test_random_nonuniform_schedules_equal_the_uniform_convolution(hip, seed):
+    rng = np.random.default_rng(9000 + seed)
+    rs = int(rng.choice([4, 8]))
+    L0 = int(rng.choice([64, 128]))
+    seg_len, seg_blk, off = [L0], [], 0
+    for _ in range(int(rng.integers(0, 4))):
+        seg_len.append(seg_len[-1] * int(rng.choice([2, 4])))
+    for k, Lk in enumerate(seg_len):
+        need = 1
+        if k + 1 < len(seg_len):                      # the next segment must not start too early
+            need = max(1, -(-(seg_len[k + 1] - L0 - off) // Lk))
+        nb = need + int(rng.integers(0, 3))
+        seg_blk.append(nb)
+        off += nb * Lk
+    n_in, n_out = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+    nu = hip.Nupc(seg_len, seg_blk, rs, n_in, n_out)
+    infmt = str(rng.choice(["S16_LE", "S24_4LE", "FLOAT_LE"]))
+    nu.set_interleaved(0, infmt)
+    nu.set_interleaved(1, FLOATFMT[rs])
+    taps = int(rng.integers(1, nu.taps + 1))
+    oN = -(-taps // L0)
+    oe = bo.Engine(L0, oN, rs, n_in, n_out)
+    oe.set_interleaved(0, infmt)
+    oe.set_interleaved(1, FLOATFMT[rs])
+    dt = np.float32 if rs == 4 else np.float64
+    for o in range(n_out):
+        for i in range(n_in):
+            if rng.random() < 0.2:
+                continue
+            h = cases.make_ir(rng, taps, n_in).astype(dt)
+            si, so = float(rng.choice([1.0, -0.5])), float(rng.choice([1.0, 0.25]))
+            nu.add_filter(i, o, h, in_scale=si, out_scale=so)
+            oe.add_filter(in_ch=[i], out_ch=[o], coeff=oe.add_coeff(h), in_scale=[si], out_scale=[so])
+    nu.finalize()
+    n_blocks = int(2.5 * nu.taps / L0) + 4
+    tol = 1e-5 if rs == 4 else 1e-12
+    for b, blk in enumerate(cases.raw_blocks(seed, n_blocks, L0, n_in, infmt, amplitude=0.2)):
+        sg, g = nu.block(blk)
+        so_, o = oe.block(blk)
+        assert sg == so_ == 0
+        gs = np.frombuffer(g.tobytes(), dt).astype(np.float64).reshape(L0, n_out)
+        os_ = np.frombuffer(o.tobytes(), dt).astype(np.float64).reshape(L0, n_out)
+        for ch in range(n_out):
+            err = float(np.sqrt(((gs[:, ch] - os_[:, ch]) ** 2).mean()))
+            lvl = max(float(np.sqrt((os_[:, ch] ** 2).mean())), FLOOR)
+            assert err <= tol * lvl, (seed, b, ch, err, lvl, seg_len, seg_blk)
