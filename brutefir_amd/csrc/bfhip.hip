@@ -26,6 +26,7 @@
 
 #include "../../include/bfhip.h"
 #include "kernels.h"
+#include "bigfft.h"
 
 using namespace bfhip;
 
@@ -181,6 +182,13 @@ struct bfhip_engine {
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_mac[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
     int R = 0;                         // depth of the input rings
     void *d_Zp2 = nullptr;             // second partial-spectra buffer
+
+    // partition lengths above the LDS limit (bigfft.h): global scratch for [transform][L] complex
+    bool big = false;
+    int big_R = 1;                 // L / 8192
+    void *d_big[3] = {nullptr, nullptr, nullptr};   // zin, zmid, zout
+    size_t big_cap = 0;            // transforms the scratch holds
+    void *d_tw13 = nullptr;        // twiddle table of the 8192-point LDS transform
 
     // device state
     void *d_tw = nullptr;          // [2L] complex
@@ -367,20 +375,10 @@ void launch_coeff_prep(bfhip_engine *e, const void *taps, int n_taps, double sca
     *err = hipGetLastError();
 }
 
-template <typename T, int LOG2L>
-void launch_ifft_out(bfhip_engine *e, const void *Zp, size_t chunk_stride, int n_chunks,
-                     int first, int count, uint8_t *raw, hipError_t *err) {
-    constexpr int NT = fft_threads<T>(LOG2L);
-    const size_t lds = lds_fft_bytes(LOG2L, sizeof(c2<T>));
-    auto k = ifft_out_kernel<T, LOG2L>;
-    *err = allow_lds(k, lds);
-    if (*err != hipSuccess) return;
-    hipLaunchKernelGGL(k, dim3(count), dim3(NT), lds, e->ls, (const c2<T> *)Zp, chunk_stride,
-                       n_chunks, first, e->d_fmt[1], e->d_over, (const unsigned char *)e->d_skip_quant,
-                       raw, e->d_timeout ? (T *)e->d_timeout + (size_t)first * e->L : (T *)nullptr,
-                       (const c2<T> *)e->d_tw, e->safety_limit, e->d_status);
-    *err = hipGetLastError();
-    if (*err != hipSuccess || e->dither_channels.empty()) return;
+// the HP-TPDF pass over the channels of [first, first+count) that dither (after K3)
+template <typename T>
+void launch_dither(bfhip_engine *e, int first, int count, uint8_t *raw, hipError_t *err) {
+    if (e->dither_channels.empty()) return;
     // dither slots whose channel lies in [first, first+count): the slots are sorted by channel
     int s0 = 0, s1 = 0;
     for (size_t i = 0; i < e->dither_channels.size(); i++) {
@@ -395,6 +393,23 @@ void launch_ifft_out(bfhip_engine *e, const void *Zp, size_t chunk_stride, int n
                            e->d_fmt[1], e->d_over, raw, e->L, e->safety_limit, e->d_status);
         *err = hipGetLastError();
     }
+}
+
+template <typename T, int LOG2L>
+void launch_ifft_out(bfhip_engine *e, const void *Zp, size_t chunk_stride, int n_chunks,
+                     int first, int count, uint8_t *raw, hipError_t *err) {
+    constexpr int NT = fft_threads<T>(LOG2L);
+    const size_t lds = lds_fft_bytes(LOG2L, sizeof(c2<T>));
+    auto k = ifft_out_kernel<T, LOG2L>;
+    *err = allow_lds(k, lds);
+    if (*err != hipSuccess) return;
+    hipLaunchKernelGGL(k, dim3(count), dim3(NT), lds, e->ls, (const c2<T> *)Zp, chunk_stride,
+                       n_chunks, first, e->d_fmt[1], e->d_over, (const unsigned char *)e->d_skip_quant,
+                       raw, e->d_timeout ? (T *)e->d_timeout + (size_t)first * e->L : (T *)nullptr,
+                       (const c2<T> *)e->d_tw, e->safety_limit, e->d_status);
+    *err = hipGetLastError();
+    if (*err != hipSuccess) return;
+    launch_dither<T>(e, first, count, raw, err);
 }
 
 template <typename T, int LOG2L>
@@ -479,6 +494,147 @@ void launch_levels(bfhip_engine *e, hipError_t *err) {
         if ((*err = hipGetLastError()) != hipSuccess) return;
     }
 }
+
+
+// ---------------------------------------------------------------- block lengths above 8192 (bigfft.h)
+
+// scratch for n_tr transforms of L complex points each (zin, zmid, zout)
+int big_reserve(bfhip_engine *e, size_t n_tr) {
+    if (n_tr <= e->big_cap) return BFHIP_OK;
+    { int r = sync_all(e); if (r != BFHIP_OK) return r; }
+    for (int i = 0; i < 3; i++) {
+        if (e->d_big[i]) (void)hipFree(e->d_big[i]);
+        e->d_big[i] = nullptr;
+        HIPCHK(hipMalloc(&e->d_big[i], n_tr * (size_t)e->L * e->csize()));
+    }
+    e->big_cap = n_tr;
+    return BFHIP_OK;
+}
+
+// zin -> zout: complex FFT of L points for n_tr transforms on `st`
+template <typename T>
+void big_fft(bfhip_engine *e, int n_tr, bool inv, hipStream_t st, hipError_t *err) {
+    constexpr int NT = fft_threads<T>(BIG_LOG2M);
+    const size_t lds = lds_fft_bytes(BIG_LOG2M, sizeof(c2<T>));
+    const c2<T> *zin = (const c2<T> *)e->d_big[0];
+    c2<T> *zmid = (c2<T> *)e->d_big[1], *zout = (c2<T> *)e->d_big[2];
+    const c2<T> *tw13 = (const c2<T> *)e->d_tw13, *twL = (const c2<T> *)e->d_tw;
+    const int R = e->big_R;
+    if (inv) {
+        auto ka = big_fft_a<T, true>;
+        if ((*err = allow_lds(ka, lds)) != hipSuccess) return;
+        hipLaunchKernelGGL(ka, dim3(R, n_tr), dim3(NT), lds, st, zin, zmid, R, tw13);
+        const dim3 gb(BIG_M / 256, n_tr);
+        if (R == 2) hipLaunchKernelGGL((big_fft_b<T, true, 2>), gb, dim3(256), 0, st, (const c2<T> *)zmid, zout, twL);
+        else if (R == 4) hipLaunchKernelGGL((big_fft_b<T, true, 4>), gb, dim3(256), 0, st, (const c2<T> *)zmid, zout, twL);
+        else hipLaunchKernelGGL((big_fft_b<T, true, 8>), gb, dim3(256), 0, st, (const c2<T> *)zmid, zout, twL);
+    } else {
+        auto ka = big_fft_a<T, false>;
+        if ((*err = allow_lds(ka, lds)) != hipSuccess) return;
+        hipLaunchKernelGGL(ka, dim3(R, n_tr), dim3(NT), lds, st, zin, zmid, R, tw13);
+        const dim3 gb(BIG_M / 256, n_tr);
+        if (R == 2) hipLaunchKernelGGL((big_fft_b<T, false, 2>), gb, dim3(256), 0, st, (const c2<T> *)zmid, zout, twL);
+        else if (R == 4) hipLaunchKernelGGL((big_fft_b<T, false, 4>), gb, dim3(256), 0, st, (const c2<T> *)zmid, zout, twL);
+        else hipLaunchKernelGGL((big_fft_b<T, false, 8>), gb, dim3(256), 0, st, (const c2<T> *)zmid, zout, twL);
+    }
+    *err = hipGetLastError();
+}
+
+inline dim3 big_grid_half(const bfhip_engine *e, int n_tr) { return dim3((unsigned)(e->L / 2 / 256 + 1), (unsigned)n_tr); }
+
+template <typename T>
+void launch_fft_in_big(bfhip_engine *e, const uint8_t *raw, int slot, hipError_t *err) {
+    const int n = e->n_ch[0];
+    hipLaunchKernelGGL(big_in_pre<T>, big_grid_half(e, n), dim3(256), 0, e->ls, raw, e->d_fmt[0], (T *)e->d_prev,
+                       (c2<T> *)e->d_big[0], e->L);
+    big_fft<T>(e, n, false, e->ls, err);
+    if (*err != hipSuccess) return;
+    hipLaunchKernelGGL(big_untangle<T>, big_grid_half(e, n), dim3(256), 0, e->ls, (const c2<T> *)e->d_big[2],
+                       (c2<T> *)e->d_ring + (size_t)slot * e->L, (size_t)e->R * e->L, (const c2<T> *)e->d_tw, e->L, (T)1);
+    *err = hipGetLastError();
+}
+
+template <typename T>
+void launch_coeff_prep_big(bfhip_engine *e, const void *taps, int n_taps, double scale, void *H,
+                           int n_blocks, hipError_t *err) {
+    hipStream_t keep = e->ls;
+    e->ls = e->stream;
+    hipLaunchKernelGGL(big_coeff_pre<T>, big_grid_half(e, n_blocks), dim3(256), 0, e->stream, (const T *)taps, n_taps,
+                       (T)scale, (c2<T> *)e->d_big[0], e->L, e->d_bad);
+    big_fft<T>(e, n_blocks, false, e->stream, err);
+    if (*err == hipSuccess) {
+        hipLaunchKernelGGL(big_untangle<T>, big_grid_half(e, n_blocks), dim3(256), 0, e->stream, (const c2<T> *)e->d_big[2],
+                           (c2<T> *)H, (size_t)e->L, (const c2<T> *)e->d_tw, e->L, (T)1.0 / (T)(2 * e->L));
+        *err = hipGetLastError();
+    }
+    e->ls = keep;
+}
+
+template <typename T>
+void launch_ifft_out_big(bfhip_engine *e, const void *Zp, size_t chunk_stride, int n_chunks,
+                         int first, int count, uint8_t *raw, hipError_t *err) {
+    hipLaunchKernelGGL(big_out_pre<T>, big_grid_half(e, count), dim3(256), 0, e->ls, (const c2<T> *)Zp, chunk_stride,
+                       n_chunks, (c2<T> *)e->d_big[0], (const c2<T> *)e->d_tw, e->L);
+    big_fft<T>(e, count, true, e->ls, err);
+    if (*err != hipSuccess) return;
+    hipLaunchKernelGGL(big_out_post<T>, dim3(count), dim3(1024), 0, e->ls, (const c2<T> *)e->d_big[2], first, e->d_fmt[1],
+                       e->d_over, (const unsigned char *)e->d_skip_quant, raw,
+                       e->d_timeout ? (T *)e->d_timeout + (size_t)first * e->L : (T *)nullptr, e->L, e->safety_limit,
+                       e->d_status);
+    *err = hipGetLastError();
+    if (*err != hipSuccess) return;
+    launch_dither<T>(e, first, count, raw, err);
+}
+
+template <typename T>
+void launch_levels_big(bfhip_engine *e, hipError_t *err) {
+    const unsigned long long age64 = std::min<unsigned long long>(e->blocks_done + 1, (unsigned long long)e->N);
+    const unsigned char *base = (const unsigned char *)e->d_jobs;
+    const int V = 16 / (int)sizeof(c2<T>);
+    const int threads = e->mac_threads;
+    const int tiles = (e->L + threads * V - 1) / (threads * V);
+    const c2<T> *twL = (const c2<T> *)e->d_tw;
+    for (auto &lj : e->level_jobs) {
+        if (lj.n_fill > 0) {
+            const FillJob<T> *jobs = (const FillJob<T> *)(base + lj.fill_off);
+            const MixSrc<T> *src = (const MixSrc<T> *)(base + e->src_off);
+            hipLaunchKernelGGL(big_fill_pre<T>, big_grid_half(e, lj.n_fill), dim3(256), 0, e->ls, jobs, src,
+                               (c2<T> *)e->d_big[0], twL, e->L);
+            big_fft<T>(e, lj.n_fill, true, e->ls, err);
+            if (*err != hipSuccess) return;
+            hipLaunchKernelGGL(big_fill_slide<T>, big_grid_half(e, lj.n_fill), dim3(256), 0, e->ls, jobs,
+                               (const c2<T> *)e->d_big[2], (c2<T> *)e->d_big[0], e->L);
+            big_fft<T>(e, lj.n_fill, false, e->ls, err);
+            if (*err != hipSuccess) return;
+            hipLaunchKernelGGL(big_fill_post<T>, big_grid_half(e, lj.n_fill), dim3(256), 0, e->ls, jobs, src,
+                               (const c2<T> *)e->d_big[2], twL, e->N, e->blockcounter, e->L, (const BlockState *)e->bs_arg);
+        }
+        if (lj.n_filt > 0) {
+            hipLaunchKernelGGL(mac_filter_kernel<T>, dim3(tiles, lj.n_filt), dim3(threads), 0, e->ls,
+                               (const FilterJob<T> *)(base + lj.filt_off), e->L, e->blockcounter, (int)age64,
+                               (const BlockState *)e->bs_arg);
+        }
+        if (lj.n_fade > 0) {
+            const FadeJob<T> *jobs = (const FadeJob<T> *)(base + lj.fade_off);
+            hipLaunchKernelGGL(big_fade_pre<T>, big_grid_half(e, 2 * lj.n_fade), dim3(256), 0, e->ls, jobs,
+                               (c2<T> *)e->d_big[0], twL, e->L);
+            big_fft<T>(e, 2 * lj.n_fade, true, e->ls, err);
+            if (*err != hipSuccess) return;
+            hipLaunchKernelGGL(big_fade_mix<T>, dim3((unsigned)(e->L / 256), (unsigned)lj.n_fade), dim3(256), 0, e->ls,
+                               (const c2<T> *)e->d_big[2], (c2<T> *)e->d_big[0], e->L);
+            big_fft<T>(e, lj.n_fade, false, e->ls, err);
+            if (*err != hipSuccess) return;
+            hipLaunchKernelGGL(big_fade_post<T>, big_grid_half(e, lj.n_fade), dim3(256), 0, e->ls, jobs,
+                               (const c2<T> *)e->d_big[2], twL, e->L);
+        }
+        if ((*err = hipGetLastError()) != hipSuccess) return;
+    }
+}
+
+#define DISPATCH_BIG(FN, ...)                                               \
+    do {                                                                    \
+        if (e->rs == 4) FN<float>(__VA_ARGS__); else FN<double>(__VA_ARGS__); \
+    } while (0)
 
 // ---------------------------------------------------------------- plan
 
@@ -1001,7 +1157,9 @@ int do_inputs(bfhip_engine *e, const void *rawin_dev) {
     { int rv = do_subdelay(e, 0, rawin_dev); if (rv != BFHIP_OK) return rv; }
     hipError_t err = hipSuccess;
     const int slot = (int)(e->blockcounter % (unsigned int)e->R);
-    DISPATCH(launch_fft_in, e, (const uint8_t *)rawin_dev, slot, &err);
+    if (e->big) { int rr = big_reserve(e, (size_t)e->n_ch[0]); if (rr != BFHIP_OK) return rr; }
+    if (e->big) DISPATCH_BIG(launch_fft_in_big, e, (const uint8_t *)rawin_dev, slot, &err);
+    else DISPATCH(launch_fft_in, e, (const uint8_t *)rawin_dev, slot, &err);
     if (err != hipSuccess) return fail(BFHIP_EHIP, "fft_in launch: %s", hipGetErrorString(err));
     return BFHIP_OK;
 }
@@ -1011,7 +1169,14 @@ int do_levels(bfhip_engine *e) {
     for (auto &lj : e->level_jobs) any = any || lj.n_fill || lj.n_filt || lj.n_fade;
     if (!any) return BFHIP_OK;
     hipError_t err = hipSuccess;
-    DISPATCH(launch_levels, e, &err);
+    if (e->big) {
+        size_t need = 1;
+        for (auto &lj : e->level_jobs) need = std::max(need, std::max((size_t)lj.n_fill, (size_t)2 * lj.n_fade));
+        int rr = big_reserve(e, need);
+        if (rr != BFHIP_OK) return rr;
+    }
+    if (e->big) DISPATCH_BIG(launch_levels_big, e, &err);
+    else DISPATCH(launch_levels, e, &err);
     if (err != hipSuccess) return fail(BFHIP_EHIP, "level kernels: %s", hipGetErrorString(err));
     return BFHIP_OK;
 }
@@ -1029,7 +1194,9 @@ int do_outputs(bfhip_engine *e, const void *Zp, size_t chunk_stride, int n_chunk
     if (count <= 0) return BFHIP_OK;
     if (!e->vout_groups.empty() && (first != 0 || count != e->n_ch[1]))
         return fail(BFHIP_EINVAL, "outputs that share a physical channel cannot be split over several calls");
-    DISPATCH(launch_ifft_out, e, Zp, chunk_stride, n_chunks, first, count, (uint8_t *)rawout_dev, &err);
+    if (e->big) { int rr = big_reserve(e, (size_t)count); if (rr != BFHIP_OK) return rr; }
+    if (e->big) DISPATCH_BIG(launch_ifft_out_big, e, Zp, chunk_stride, n_chunks, first, count, (uint8_t *)rawout_dev, &err);
+    else DISPATCH(launch_ifft_out, e, Zp, chunk_stride, n_chunks, first, count, (uint8_t *)rawout_dev, &err);
     if (err != hipSuccess) return fail(BFHIP_EHIP, "ifft_out launch: %s", hipGetErrorString(err));
     { int rv = do_subdelay(e, 1, nullptr); if (rv != BFHIP_OK) return rv; }
     return do_vout(e, rawout_dev);
@@ -1069,7 +1236,7 @@ void rt_release(bfhip_engine *e) {
 
 // can this plan's launch sequence be replayed unchanged block after block?
 bool rt_graphable(const bfhip_engine *e) {
-    if (e->rt.flags & (BFHIP_RT_NO_GRAPH | BFHIP_RT_OVERLAP)) return false;
+    if ((e->rt.flags & (BFHIP_RT_NO_GRAPH | BFHIP_RT_OVERLAP)) || e->big) return false;
     // N:1 channels and sub-sample delays upload a per-block job table; a cross-fade lasts one block
     return !e->has_vchan && !side_uses_subdelay(e, 0) && !side_uses_subdelay(e, 1) && !e->any_fading;
 }
@@ -1245,8 +1412,8 @@ bfhip_engine *bfhip_engine_create(int device, int length, int n_blocks, int real
                                   int n_in, int n_out) {
     if (realsize != 4 && realsize != 8) { fail(BFHIP_EINVAL, "Invalid real size %d.", realsize); return nullptr; }
     const int lg = ilog2(length);
-    if (lg < 6 || lg > 13) {
-        fail(BFHIP_EINVAL, "Invalid length %d (power of two in 64..8192 required).", length);
+    if (lg < 6 || lg > 16) {
+        fail(BFHIP_EINVAL, "Invalid length %d (power of two in 64..65536 required).", length);
         return nullptr;
     }
     if (n_blocks < 1 || n_in < 1 || n_out < 1) { fail(BFHIP_EINVAL, "bad n_blocks/n_in/n_out"); return nullptr; }
@@ -1260,6 +1427,8 @@ bfhip_engine *bfhip_engine_create(int device, int length, int n_blocks, int real
 
     bfhip_engine *e = new bfhip_engine();
     e->device = device; e->L = length; e->N = n_blocks; e->rs = realsize; e->log2L = lg;
+    e->big = lg > BIG_LOG2M;
+    e->big_R = e->big ? length / BIG_M : 1;
     e->n_ch[0] = n_in; e->n_ch[1] = n_out;
     for (int io = 0; io < 2; io++) {
         e->fmt[io].resize(e->n_ch[io]);
@@ -1289,6 +1458,12 @@ bfhip_engine *bfhip_engine_create(int device, int length, int n_blocks, int real
         realsize == 4 ? fft_threads<float>(log2l) : fft_threads<double>(log2l));
     ok = ok && hipMalloc(&e->d_tw, tw.size()) == hipSuccess;
     ok = ok && hipMemcpy(e->d_tw, tw.data(), tw.size(), hipMemcpyHostToDevice) == hipSuccess;
+    if (e->big) {
+        const std::vector<unsigned char> tw13 = make_twiddle_table(BIG_LOG2M, realsize,
+            realsize == 4 ? fft_threads<float>(BIG_LOG2M) : fft_threads<double>(BIG_LOG2M));
+        ok = ok && hipMalloc(&e->d_tw13, tw13.size()) == hipSuccess;
+        ok = ok && hipMemcpy(e->d_tw13, tw13.data(), tw13.size(), hipMemcpyHostToDevice) == hipSuccess;
+    }
     ok = ok && hipMalloc((void **)&e->d_bad, sizeof(int)) == hipSuccess;
     ok = ok && hipMemset(e->d_bad, 0, sizeof(int)) == hipSuccess;
     if (!ok) {
@@ -1323,7 +1498,8 @@ void bfhip_engine_destroy(bfhip_engine *e) {
     void *ptrs[] = {e->d_tw, e->d_prev, e->d_ring, e->d_fmt[0], e->d_fmt[1], e->d_over, e->d_status,
                     e->d_bad, e->d_Zp, e->d_entries, e->d_chunks, e->d_rawin, e->d_rawout, e->d_taps,
                     e->d_fring, e->d_Y, e->d_Yold, e->d_evalprev, e->d_jobs,
-                    e->d_dither_ch, e->d_dither_state, e->d_dither_table, e->d_randmap, e->d_skip_quant, e->d_timeout};
+                    e->d_dither_ch, e->d_dither_state, e->d_dither_table, e->d_randmap, e->d_skip_quant, e->d_timeout,
+                    e->d_big[0], e->d_big[1], e->d_big[2], e->d_tw13};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto ev : e->ev) (void)hipEventDestroy(ev);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -1503,7 +1679,10 @@ static int add_coeff_common(bfhip_engine *e, const void *taps, bool on_device, i
     if (hipMalloc(&c.d_H, (size_t)n_blocks * L * e->csize()) != hipSuccess)
         return fail(BFHIP_ENOMEM, "out of device memory for coefficient set");
     hipError_t err = hipSuccess;
-    DISPATCH(launch_coeff_prep, e, src, n_taps, scale, c.d_H, n_blocks, &err);
+    if (e->big) {
+        { int rr = big_reserve(e, (size_t)n_blocks); if (rr != BFHIP_OK) { (void)hipFree(c.d_H); return rr; } }
+        DISPATCH_BIG(launch_coeff_prep_big, e, src, n_taps, scale, c.d_H, n_blocks, &err);
+    } else DISPATCH(launch_coeff_prep, e, src, n_taps, scale, c.d_H, n_blocks, &err);
     if (err != hipSuccess) { (void)hipFree(c.d_H); return fail(BFHIP_EHIP, "coeff_prep launch: %s", hipGetErrorString(err)); }
     if (!on_device) {
         // host-taps path is synchronous, like convolver_coeffs2cbuf: report NaN/Inf now
@@ -1597,7 +1776,10 @@ int bfhip_engine_update_coeff_block(bfhip_engine *e, int coeff, int block, const
     HIPCHK(hipMemcpy(e->d_taps, taps, bytes, hipMemcpyHostToDevice));
     void *H = (unsigned char *)e->coeffs[coeff].d_H + (size_t)block * e->L * e->csize();
     hipError_t err = hipSuccess;
-    DISPATCH(launch_coeff_prep, e, e->d_taps, e->L, 1.0, H, 1, &err);
+    if (e->big) {
+        { int rr = big_reserve(e, 1); if (rr != BFHIP_OK) return rr; }
+        DISPATCH_BIG(launch_coeff_prep_big, e, e->d_taps, e->L, 1.0, H, 1, &err);
+    } else DISPATCH(launch_coeff_prep, e, e->d_taps, e->L, 1.0, H, 1, &err);
     if (err != hipSuccess) return fail(BFHIP_EHIP, "coeff_prep launch: %s", hipGetErrorString(err));
     { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
     return BFHIP_OK;
@@ -1650,6 +1832,7 @@ int bfhip_engine_finalize(bfhip_engine *e) {
         if (e->overlap_mode >= 0) e->pipelined = e->overlap_mode != 0;
         if (const char *env = getenv("BFHIP_OVERLAP")) e->pipelined = atoi(env) != 0;
         for (int io = 0; io < 2; io++) for (int c : e->n_vpp[io]) if (c > 1) e->pipelined = false;   // one job table per side
+        if (e->big) e->pipelined = false;          // one FFT scratch
     }
     e->R = e->pipelined ? e->N + 1 : e->N;
     const size_t ring_b = (size_t)e->n_ch[0] * e->R * L * e->csize();
@@ -1872,7 +2055,7 @@ int bfhip_engine_outputs_inputs_dev(bfhip_engine *e, const void *z_dev, int firs
     int r = ensure_ready(e);
     if (r != BFHIP_OK) return r;
     if (first < 0 || count < 0 || first + count > e->n_ch[1]) return fail(BFHIP_EINVAL, "outputs: channel range");
-    if (!e->dither_channels.empty() || e->has_vchan || count == 0) {
+    if (!e->dither_channels.empty() || e->has_vchan || count == 0 || e->big) {
         // the dither pass follows the inverse transforms: keep the two launches apart
         if ((r = bfhip_engine_outputs_dev(e, z_dev, first, count, rawout_dev)) != BFHIP_OK) return r;
         return bfhip_engine_inputs_dev(e, rawin_dev);

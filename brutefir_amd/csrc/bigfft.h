@@ -1,0 +1,384 @@
+// bigfft.h -- partition lengths above the LDS limit (L = 16384 ... 65536).
+//
+// BruteFIR's stock configuration is ONE partition of 65536 taps (`filter_length: 65536;`,
+// bfconf.c:197, bench3_config) and any power of two is legal (bfconf.c:1512-1514).  A complex
+// FFT of more than 8192 points does not fit a CU's LDS, so for these lengths every
+// FFT-bearing kernel of kernels.h is replaced by a short sequence over global scratch buffers:
+//
+//     pre   (elementwise: window / tangle / mix ...  -> zin[transform][L])
+//     A     R = L/8192 LDS transforms of M = 8192 points per transform, on the decimated
+//           subsequences z[r + R m]                        -> zmid[transform][r][k]
+//     B     radix-R combine with twiddles W_L^(r k)         -> zout[transform][k + M q]
+//     post  (elementwise: untangle / quantise / ramp ...)
+//
+// (decimation in time: X[k + M q] = sum_r W_R^(r q) (W_L^(r k) Y_r[k]), Y_r = FFT_M of z[r + R m]).
+// The block period at these lengths is a third of a second and more; the extra launches and
+// the global round trips do not matter, the MAC (kernels.h, any L) still dominates.
+// Arithmetic and bookkeeping are the same statements as in the LDS kernels, so every feature
+// (cascades, cross-fades, dither, N:1 channels ...) keeps working unchanged.
+#pragma once
+#include "kernels.h"
+
+namespace bfhip {
+
+constexpr int BIG_LOG2M = 13;
+constexpr int BIG_M = 1 << BIG_LOG2M;
+
+// ---- stage A: R x n_tr workgroups, each one M-point LDS FFT of a decimated subsequence
+template <typename T, bool INV>
+__global__ __launch_bounds__(fft_threads<T>(BIG_LOG2M)) void
+big_fft_a(const c2<T> *__restrict__ zin, c2<T> *__restrict__ zmid, int R, const c2<T> *__restrict__ tw13) {
+    constexpr int NT = fft_threads<T>(BIG_LOG2M), M = BIG_M;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    LdsArr<T> s{reinterpret_cast<c2<T> *>(smem)};
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const size_t base = (size_t)blockIdx.y * M * R;
+    TwRegs<T, BIG_LOG2M, NT> twr;
+    for (int m = tid; m < M; m += NT) s[m] = zin[base + (size_t)r + (size_t)R * m];
+    twr.prefetch(tw13);
+    __syncthreads();
+    lds_fft<T, BIG_LOG2M, NT, INV>(s, twr);
+    for (int k = tid; k < M; k += NT) zmid[base + (size_t)r * M + k] = s[k];
+}
+
+// ---- stage B: one thread per k in [0, M): twiddle, DFT_R across the R partial transforms
+template <typename T, bool INV, int R>
+__global__ __launch_bounds__(256) void
+big_fft_b(const c2<T> *__restrict__ zmid, c2<T> *__restrict__ zout, const c2<T> *__restrict__ twL) {
+    constexpr int M = BIG_M;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const size_t base = (size_t)blockIdx.y * M * R;
+    c2<T> u[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        u[r] = zmid[base + (size_t)r * M + k];
+        if (r > 0) {
+            c2<T> w = twL[2 * (r * k)];                 // exp(-2 pi i r k / L)
+            if (INV) w.y = -w.y;
+            u[r] = cmul(u[r], w);
+        }
+    }
+    dftR<T, INV, R>(u);
+#pragma unroll
+    for (int q = 0; q < R; q++) zout[base + (size_t)k + (size_t)M * q] = u[q];
+}
+
+// ---- K1 ------------------------------------------------------------------------------------
+
+// window [previous L | new L] packed as z[n] = x[2n] + i x[2n+1] (fft_in_body's first half)
+template <typename T>
+__global__ __launch_bounds__(256) void
+big_in_pre(const uint8_t *__restrict__ raw, const DevFormat *__restrict__ fmt, T *__restrict__ prev,
+           c2<T> *__restrict__ zin, int L) {
+    const int n = blockIdx.x * 256 + threadIdx.x, ch = blockIdx.y;
+    if (n >= L / 2) return;
+    const DevFormat f = fmt[ch];
+    c2<T> *pv = reinterpret_cast<c2<T> *>(prev + (size_t)ch * L);
+    const uint8_t *base = f.alt ? f.alt : raw + f.byte_offset;
+    const size_t stride = (size_t)f.sample_spacing * f.bytes;
+    const c2<T> cur = mk<T>(load_raw<T>(base + (size_t)(2 * n) * stride, f),
+                            load_raw<T>(base + (size_t)(2 * n + 1) * stride, f));
+    zin[(size_t)ch * L + n] = pv[n];
+    zin[(size_t)ch * L + L / 2 + n] = cur;
+    pv[n] = cur;
+}
+
+// complex FFT of the packed window -> packed spectrum of the 2L real samples, times `scale`;
+// transform t goes to dst0 + t * dst_stride (elements)
+template <typename T>
+__global__ __launch_bounds__(256) void
+big_untangle(const c2<T> *__restrict__ zout, c2<T> *__restrict__ dst0, size_t dst_stride,
+             const c2<T> *__restrict__ twL, int L, T scale) {
+    const int k = blockIdx.x * 256 + threadIdx.x, t = blockIdx.y;
+    if (k > L / 2) return;
+    const c2<T> *s = zout + (size_t)t * L;
+    c2<T> *out = dst0 + (size_t)t * dst_stride;
+    if (k == 0) { out[0] = mk<T>((s[0].x + s[0].y) * scale, (s[0].x - s[0].y) * scale); return; }
+    c2<T> xk, xlk;
+    untangle(s[k], conj(s[L - k]), twL[k], xk, xlk);
+    out[k] = mk<T>(xk.x * scale, xk.y * scale);
+    if (k != L - k) out[L - k] = mk<T>(xlk.x * scale, xlk.y * scale);
+}
+
+// ---- K7 ------------------------------------------------------------------------------------
+
+template <typename T>
+__global__ __launch_bounds__(256) void
+big_coeff_pre(const T *__restrict__ taps, int n_taps, T scale, c2<T> *__restrict__ zin, int L,
+              int *__restrict__ bad) {
+    const int n = blockIdx.x * 256 + threadIdx.x, part = blockIdx.y;
+    if (n >= L / 2) return;
+    const long i0 = (long)part * L + 2 * n, i1 = i0 + 1;
+    const T a = i0 < n_taps ? taps[i0] * scale : (T)0;
+    const T b = i1 < n_taps ? taps[i1] * scale : (T)0;
+    if (!isfinite(a) || !isfinite(b)) atomicOr(bad, 1);
+    zin[(size_t)part * L + n] = mk<T>((T)0, (T)0);
+    zin[(size_t)part * L + L / 2 + n] = mk<T>(a, b);
+}
+
+// ---- K3 ------------------------------------------------------------------------------------
+
+// sum of the chunk partials (in chunk order) + C2R pre-pass (ifft_out_body's first half)
+template <typename T>
+__global__ __launch_bounds__(256) void
+big_out_pre(const c2<T> *__restrict__ Zp, size_t chunk_stride, int n_chunks, c2<T> *__restrict__ zin,
+            const c2<T> *__restrict__ twL, int L) {
+    const int k = blockIdx.x * 256 + threadIdx.x, zi = blockIdx.y;
+    if (k > L / 2) return;
+    const c2<T> *z = Zp + (size_t)zi * L;
+    c2<T> *s = zin + (size_t)zi * L;
+    c2<T> a = z[k], b = z[k == 0 ? 0 : L - k];
+    for (int c = 1; c < n_chunks; c++) {
+        const c2<T> *zc = z + (size_t)c * chunk_stride;
+        a = a + zc[k];
+        b = b + zc[k == 0 ? 0 : L - k];
+    }
+    if (k == 0) { s[0] = mk<T>(a.x + a.y, a.x - a.y); return; }
+    c2<T> zk, zlk;
+    tangle(a, conj(b), twL[k], zk, zlk);
+    s[k] = zk;
+    if (k != L - k) s[L - k] = zlk;
+}
+
+// cbuf2raw of the first L samples (pairs zout[n], n < L/2): the statements of ifft_out_body's
+// second half, one workgroup per output channel
+template <typename T>
+__global__ __launch_bounds__(1024) void
+big_out_post(const c2<T> *__restrict__ zout, int first_channel, const DevFormat *__restrict__ fmt,
+             DevOverflow *__restrict__ over, const unsigned char *__restrict__ skip_quant,
+             uint8_t *__restrict__ raw, T *__restrict__ timeout, int L, double safety_limit,
+             int *__restrict__ status) {
+    constexpr int NT = 1024;
+    __shared__ unsigned int red_n[16];
+    __shared__ int32_t red_i[16];
+    __shared__ double red_l[16];
+    __shared__ int red_s[16];
+    const int zi = blockIdx.x, tid = threadIdx.x, ch = first_channel + zi;
+    const c2<T> *s = zout + (size_t)zi * L;
+    const DevFormat f = fmt[ch];
+    DevOverflow of = over[ch];
+    const bool quant = skip_quant == nullptr || !skip_quant[ch];
+    uint8_t *base = raw + f.byte_offset;
+    const size_t stride = (size_t)f.sample_spacing * f.bytes;
+    const int bits = f.sbytes << 3;
+    const int32_t imin = (int32_t)(-((uint64_t)1 << (bits - 1)));
+    const int32_t imax = (int32_t)(((uint64_t)1 << (bits - 1)) - 1);
+    const double rmin_i = (double)(T)imin, rmax_i = (double)(T)imax;
+    const T rmin_f = (T)(-of.max), rmax_f = (T)of.max;
+    unsigned int n_over = 0;
+    int32_t intlargest = of.intlargest;
+    double largest = of.largest;
+    int st = 0;
+    for (int n = tid; n < L / 2; n += NT) {
+        const c2<T> zz = s[n];
+        T xs[2] = {zz.x, zz.y};
+        if (timeout != nullptr) {
+            timeout[(size_t)zi * L + 2 * n] = xs[0];
+            timeout[(size_t)zi * L + 2 * n + 1] = xs[1];
+        }
+        if (!quant) continue;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const T x = xs[q];
+            uint8_t *p = base + (size_t)(2 * n + q) * stride;
+            uint8_t tb[8];
+            if (!isfinite(x)) { st |= 1; continue; }
+            if (safety_limit != 0.0 && ((double)x < -safety_limit * of.max || (double)x > safety_limit * of.max)) {
+                st |= 2; continue;
+            }
+            if (f.isfloat) {
+                if (x < (T)0) {
+                    if (x < rmin_f) n_over++;
+                    if ((double)x < -largest) largest = -(double)x;
+                } else {
+                    if (x > rmax_f) n_over++;
+                    if ((double)x > largest) largest = (double)x;
+                }
+                if (f.bytes == 4) {
+                    const uint32_t u = __float_as_uint((float)x);
+                    tb[0] = u & 0xff; tb[1] = (u >> 8) & 0xff; tb[2] = (u >> 16) & 0xff; tb[3] = u >> 24;
+                } else {
+                    const uint64_t u = (uint64_t)__double_as_longlong((double)x);
+#pragma unroll
+                    for (int i = 0; i < 8; i++) tb[i] = (u >> (8 * i)) & 0xff;
+                }
+            } else {
+                const int32_t v = real2int_no_dither((double)x, rmin_i, rmax_i, imin, imax, n_over, intlargest, largest);
+                const uint32_t u = (uint32_t)v;
+                tb[0] = u & 0xff; tb[1] = (u >> 8) & 0xff; tb[2] = (u >> 16) & 0xff; tb[3] = u >> 24;
+            }
+            store_raw_bytes(p, tb, f.bytes, f.swap);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        n_over += __shfl_down(n_over, off);
+        const int32_t oi = __shfl_down(intlargest, off);
+        intlargest = oi > intlargest ? oi : intlargest;
+        const double ol = __shfl_down(largest, off);
+        largest = ol > largest ? ol : largest;
+        st |= __shfl_down(st, off);
+    }
+    const int wave = tid >> 6, lane = tid & 63;
+    if (lane == 0) { red_n[wave] = n_over; red_i[wave] = intlargest; red_l[wave] = largest; red_s[wave] = st; }
+    __syncthreads();
+    if (tid == 0 && quant) {
+        for (int w = 1; w < NT / 64; w++) {
+            n_over += red_n[w];
+            intlargest = red_i[w] > intlargest ? red_i[w] : intlargest;
+            largest = red_l[w] > largest ? red_l[w] : largest;
+            st |= red_s[w];
+        }
+        over[ch].n_overflows = of.n_overflows + n_over;
+        over[ch].intlargest = intlargest;
+        over[ch].largest = largest;
+        if (st) atomicOr(status, st);
+    }
+}
+
+// ---- K4/K5: ring fill (see ring_fill_kernel) ---------------------------------------------------
+
+// M = sum_g fscale_g Y_g, tangled, for the jobs that have filter inputs
+template <typename T>
+__global__ __launch_bounds__(256) void
+big_fill_pre(const FillJob<T> *__restrict__ jobs, const MixSrc<T> *__restrict__ src,
+             c2<T> *__restrict__ zin, const c2<T> *__restrict__ twL, int L) {
+    const int k = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    if (k > L / 2) return;
+    const FillJob<T> job = jobs[j];
+    c2<T> *s = zin + (size_t)j * L;
+    if (job.n_up <= 0) {                                    // nothing to evaluate: keep the buffers defined
+        s[k] = mk<T>((T)0, (T)0);
+        if (k != 0 && k != L - k) s[L - k] = mk<T>((T)0, (T)0);
+        return;
+    }
+    const MixSrc<T> *up = src + job.up_off;
+    c2<T> a = mk<T>(up[0].spec[k].x * up[0].scale, up[0].spec[k].y * up[0].scale);
+    c2<T> b = mk<T>((T)0, (T)0);
+    if (k != 0) b = mk<T>(up[0].spec[L - k].x * up[0].scale, up[0].spec[L - k].y * up[0].scale);
+    for (int g = 1; g < job.n_up; g++) {
+        const c2<T> v = up[g].spec[k];
+        a = mk<T>(a.x + v.x * up[g].scale, a.y + v.y * up[g].scale);
+        if (k != 0) {
+            const c2<T> w = up[g].spec[L - k];
+            b = mk<T>(b.x + w.x * up[g].scale, b.y + w.y * up[g].scale);
+        }
+    }
+    if (k == 0) { s[0] = mk<T>(a.x + a.y, a.x - a.y); return; }
+    c2<T> zk, zlk;
+    tangle(a, conj(b), twL[k], zk, zlk);
+    s[k] = zk;
+    if (k != L - k) s[L - k] = zlk;
+}
+
+// convolver_convolve_eval's slide: window = [previous valid half | new valid half]
+template <typename T>
+__global__ __launch_bounds__(256) void
+big_fill_slide(const FillJob<T> *__restrict__ jobs, const c2<T> *__restrict__ zout, c2<T> *__restrict__ zin, int L) {
+    const int n = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    if (n >= L / 2) return;
+    const FillJob<T> job = jobs[j];
+    if (job.n_up <= 0) return;
+    c2<T> *ep = reinterpret_cast<c2<T> *>(job.evalprev);
+    const c2<T> v = zout[(size_t)j * L + n];
+    zin[(size_t)j * L + L / 2 + n] = v;
+    zin[(size_t)j * L + n] = ep[n];
+    ep[n] = v;
+}
+
+// ring[(t + delay) mod N] = sum_i scale_i X_i[t] + E   (channel inputs first, evaluated buffer last)
+template <typename T>
+__global__ __launch_bounds__(256) void
+big_fill_post(const FillJob<T> *__restrict__ jobs, const MixSrc<T> *__restrict__ src,
+              const c2<T> *__restrict__ zout, const c2<T> *__restrict__ twL, int N, unsigned int t,
+              int L, const BlockState *__restrict__ bs) {
+    const int k = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    if (k > L / 2) return;
+    if (bs) t = bs->t;
+    const FillJob<T> job = jobs[j];
+    c2<T> *dst = job.ring + (size_t)((t + (unsigned int)job.delay) % (unsigned int)N) * L;
+    const MixSrc<T> *in = src + job.in_off;
+    const c2<T> *s = zout + (size_t)j * L;
+    const int k2 = (k == 0 || k == L - k) ? -1 : L - k;
+    c2<T> a = mk<T>((T)0, (T)0), b = mk<T>((T)0, (T)0);
+    bool first = true;
+    for (int q = 0; q < job.n_in; q++) {
+        const c2<T> *sp = in[q].spec + (size_t)(t % (unsigned int)in[q].R) * L;
+        const T sc = in[q].scale;
+        const c2<T> v = sp[k];
+        if (first) a = mk<T>(v.x * sc, v.y * sc); else a = mk<T>(a.x + v.x * sc, a.y + v.y * sc);
+        if (k2 >= 0) {
+            const c2<T> w = sp[k2];
+            if (first) b = mk<T>(w.x * sc, w.y * sc); else b = mk<T>(b.x + w.x * sc, b.y + w.y * sc);
+        }
+        first = false;
+    }
+    if (job.n_up > 0) {
+        c2<T> ek, ek2 = mk<T>((T)0, (T)0);
+        if (k == 0) ek = mk<T>(s[0].x + s[0].y, s[0].x - s[0].y);
+        else untangle(s[k], conj(s[L - k]), twL[k], ek, ek2);
+        if (first) { a = ek; b = ek2; } else { a = a + ek; b = b + ek2; }
+    }
+    dst[k] = a;
+    if (k2 >= 0) dst[k2] = b;
+}
+
+// ---- K6: crossfade (see crossfade_kernel) --------------------------------------------------------
+
+// transform 2j = old-coefficient result, 2j + 1 = new-coefficient result, both tangled
+template <typename T>
+__global__ __launch_bounds__(256) void
+big_fade_pre(const FadeJob<T> *__restrict__ jobs, c2<T> *__restrict__ zin, const c2<T> *__restrict__ twL, int L) {
+    const int k = blockIdx.x * 256 + threadIdx.x, tr = blockIdx.y;
+    if (k > L / 2) return;
+    const FadeJob<T> job = jobs[tr >> 1];
+    const c2<T> *z = (tr & 1) ? (const c2<T> *)job.Ynew : job.Yold;
+    c2<T> *s = zin + (size_t)tr * L;
+    if (k == 0) { const c2<T> a = z[0]; s[0] = mk<T>(a.x + a.y, a.x - a.y); return; }
+    c2<T> zk, zlk;
+    tangle(z[k], conj(z[L - k]), twL[k], zk, zlk);
+    s[k] = zk;
+    if (k != L - k) s[L - k] = zlk;
+}
+
+// the linear ramp over the first L samples, float-branch arithmetic (fftw_convolver.c:349-355)
+template <typename T>
+__global__ __launch_bounds__(256) void
+big_fade_mix(const c2<T> *__restrict__ zout, c2<T> *__restrict__ zin, int L) {
+    const int n = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    if (n >= L) return;
+    if (n >= L / 2) { zin[(size_t)j * L + n] = zout[(size_t)(2 * j + 1) * L + n]; return; }   // second half: as computed
+    const c2<T> ov = zout[(size_t)(2 * j) * L + n];
+    c2<T> nv = zout[(size_t)(2 * j + 1) * L + n];
+    if constexpr (sizeof(T) == 4) {
+        const float f = 1.0f / (float)(L - 1);
+        const float m0 = (float)(2 * n), m1 = (float)(2 * n + 1);
+        nv.x = (float)((double)ov.x * (1.0 - (double)(f * m0)) + (double)(nv.x * f * m0));
+        nv.y = (float)((double)ov.y * (1.0 - (double)(f * m1)) + (double)(nv.y * f * m1));
+    } else {
+        const double d = 1.0 / (double)(L - 1);
+        const double m0 = (double)(2 * n), m1 = (double)(2 * n + 1);
+        nv.x = ov.x * (1.0 - d * m0) + nv.x * d * m0;
+        nv.y = ov.y * (1.0 - d * m1) + nv.y * d * m1;
+    }
+    zin[(size_t)j * L + n] = nv;
+}
+
+// back in the frequency domain: untangle, / n_fft, into the job's Ynew
+template <typename T>
+__global__ __launch_bounds__(256) void
+big_fade_post(const FadeJob<T> *__restrict__ jobs, const c2<T> *__restrict__ zout,
+              const c2<T> *__restrict__ twL, int L) {
+    const int k = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    if (k > L / 2) return;
+    const c2<T> *s = zout + (size_t)j * L;
+    c2<T> *out = jobs[j].Ynew;
+    const T inv = (T)1.0 / (T)(2 * L);
+    if (k == 0) { out[0] = mk<T>((s[0].x + s[0].y) * inv, (s[0].x - s[0].y) * inv); return; }
+    c2<T> xk, xlk;
+    untangle(s[k], conj(s[L - k]), twL[k], xk, xlk);
+    out[k] = mk<T>(xk.x * inv, xk.y * inv);
+    if (k != L - k) out[L - k] = mk<T>(xlk.x * inv, xlk.y * inv);
+}
+
+}  // namespace bfhip
