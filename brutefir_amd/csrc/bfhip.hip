@@ -316,6 +316,10 @@ int sync_all(bfhip_engine *e) {
 
 #define DISPATCH_LOG2L(T, FN, ...)                        \
     switch (e->log2L) {                                   \
+    case 2: FN<T, 2>(__VA_ARGS__); break;                 \
+    case 3: FN<T, 3>(__VA_ARGS__); break;                 \
+    case 4: FN<T, 4>(__VA_ARGS__); break;                 \
+    case 5: FN<T, 5>(__VA_ARGS__); break;                 \
     case 6: FN<T, 6>(__VA_ARGS__); break;                 \
     case 7: FN<T, 7>(__VA_ARGS__); break;                 \
     case 8: FN<T, 8>(__VA_ARGS__); break;                 \
@@ -1412,8 +1416,8 @@ bfhip_engine *bfhip_engine_create(int device, int length, int n_blocks, int real
                                   int n_in, int n_out) {
     if (realsize != 4 && realsize != 8) { fail(BFHIP_EINVAL, "Invalid real size %d.", realsize); return nullptr; }
     const int lg = ilog2(length);
-    if (lg < 6 || lg > 16) {
-        fail(BFHIP_EINVAL, "Invalid length %d (power of two in 64..65536 required).", length);
+    if (lg < 2 || lg > 16) {
+        fail(BFHIP_EINVAL, "Invalid length %d (power of two in 4..65536 required).", length);
         return nullptr;
     }
     if (n_blocks < 1 || n_in < 1 || n_out < 1) { fail(BFHIP_EINVAL, "bad n_blocks/n_in/n_out"); return nullptr; }

@@ -20,6 +20,7 @@
 
 #include "../../include/bfhip_convolver.h"
 #include "kernels.h"
+#include "bigfft.h"
 
 using namespace bfhip;
 
@@ -158,6 +159,40 @@ k_hc2r(const T *in, T *out, const c2<T> *__restrict__ tw) {
     __syncthreads();
     lds_fft<T, LOG2L, NT, true>(s, twr);
     for (int n = tid; n < L; n += NT) { const c2<T> z = s[n]; out[2 * n] = z.x; out[2 * n + 1] = z.y; }
+}
+
+// ---- transforms above the LDS limit (bigfft.h): pack / unpack around the two-stage complex FFT
+template <typename T>
+__global__ void k_big_pack(const T *in, c2<T> *zin, int L) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < L) zin[n] = mk<T>(in[2 * n], in[2 * n + 1]);
+}
+template <typename T>
+__global__ void k_big_unpack(const c2<T> *zout, T *out, int L) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < L) { const c2<T> z = zout[n]; out[2 * n] = z.x; out[2 * n + 1] = z.y; }
+}
+template <typename T>
+__global__ void k_big_r2hc_post(const c2<T> *s, T *out, const c2<T> *__restrict__ tw, int L) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > L / 2) return;
+    if (k == 0) { const c2<T> z = s[0]; out[0] = z.x + z.y; out[L] = z.x - z.y; return; }
+    c2<T> x, y;
+    untangle(s[k], conj(s[L - k]), tw[k], x, y);
+    out[k] = x.x; out[2 * L - k] = x.y;
+    if (k != L - k) { out[L - k] = y.x; out[L + k] = y.y; }
+}
+template <typename T>
+__global__ void k_big_hc2r_pre(const T *in, c2<T> *s, const c2<T> *__restrict__ tw, int L) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > L / 2) return;
+    if (k == 0) { s[0] = mk<T>(in[0] + in[L], in[0] - in[L]); return; }
+    const c2<T> a = mk<T>(in[k], in[2 * L - k]);
+    const c2<T> b = (k == L - k) ? conj(a) : mk<T>(in[L - k], -in[L + k]);
+    c2<T> zk, zlk;
+    tangle(a, b, tw[k], zk, zlk);
+    s[k] = zk;
+    if (k != L - k) s[L - k] = zlk;
 }
 
 // the ramp of convolver_crossfade_inplace, float-branch arithmetic (fftw_convolver.c:349-355)
@@ -320,6 +355,8 @@ struct State {
     pid_t pid = 0;
     hipStream_t stream = nullptr;
     std::map<int, void *> tw;          // log2(complex length) -> device twiddles
+    void *d_big[3] = {nullptr, nullptr, nullptr};   // scratch of the transforms above the LDS limit
+    size_t big_bytes[3] = {0, 0, 0};
     std::vector<void *> buf;
     std::vector<size_t> cap;
     int *d_flag = nullptr;
@@ -355,6 +392,7 @@ bool ensure_device() {
     G.pid = me;
     G.stream = nullptr;
     G.tw.clear(); G.buf.clear(); G.cap.clear(); G.d_flag = nullptr; G.d_over = nullptr;
+    for (int i = 0; i < 3; i++) { G.d_big[i] = nullptr; G.big_bytes[i] = 0; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         fatal(102, "bfhip: no HIP device available (there is no CPU fallback)");
@@ -416,8 +454,52 @@ void fft_launch(bool inverse, const void *in, void *out) {
     }
 }
 
+// 2^log2c complex points, log2c in 14..16: the input may alias the output (everything goes
+// through the scratch buffers)
+template <typename T>
+bool big_fft_launch(int log2c, bool inverse, const void *in, void *out) {
+    const int L = 1 << log2c, R = L / BIG_M;
+    const size_t bytes = (size_t)L * sizeof(c2<T>);
+    for (int i = 0; i < 3; i++) {
+        if (G.big_bytes[i] < bytes) {
+            if (G.d_big[i]) (void)hipFree(G.d_big[i]);
+            G.d_big[i] = nullptr;
+            if (hipMalloc(&G.d_big[i], bytes) != hipSuccess) { fatal(105, "bfhip: FFT scratch allocation failed"); return false; }
+            G.big_bytes[i] = bytes;
+        }
+    }
+    c2<T> *zin = (c2<T> *)G.d_big[0], *zmid = (c2<T> *)G.d_big[1], *zout = (c2<T> *)G.d_big[2];
+    const c2<T> *twL = (const c2<T> *)twiddles(log2c), *tw13 = (const c2<T> *)twiddles(BIG_LOG2M);
+    if (!twL || !tw13) return false;
+    constexpr int NT = fft_threads<T>(BIG_LOG2M);
+    const size_t lds = lds_fft_bytes(BIG_LOG2M, sizeof(c2<T>));
+    const dim3 gh((unsigned)(L / 2 / 256 + 1)), gf((unsigned)(L / 256)), gb(BIG_M / 256, 1);
+    if (inverse) hipLaunchKernelGGL(k_big_hc2r_pre<T>, gh, dim3(256), 0, G.stream, (const T *)in, zin, twL, L);
+    else hipLaunchKernelGGL(k_big_pack<T>, gf, dim3(256), 0, G.stream, (const T *)in, zin, L);
+    if (inverse) {
+        auto ka = big_fft_a<T, true>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(ka, dim3(R, 1), dim3(NT), lds, G.stream, (const c2<T> *)zin, zmid, R, tw13);
+        if (R == 2) hipLaunchKernelGGL((big_fft_b<T, true, 2>), gb, dim3(256), 0, G.stream, (const c2<T> *)zmid, zout, twL);
+        else if (R == 4) hipLaunchKernelGGL((big_fft_b<T, true, 4>), gb, dim3(256), 0, G.stream, (const c2<T> *)zmid, zout, twL);
+        else hipLaunchKernelGGL((big_fft_b<T, true, 8>), gb, dim3(256), 0, G.stream, (const c2<T> *)zmid, zout, twL);
+        hipLaunchKernelGGL(k_big_unpack<T>, gf, dim3(256), 0, G.stream, (const c2<T> *)zout, (T *)out, L);
+    } else {
+        auto ka = big_fft_a<T, false>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(ka, dim3(R, 1), dim3(NT), lds, G.stream, (const c2<T> *)zin, zmid, R, tw13);
+        if (R == 2) hipLaunchKernelGGL((big_fft_b<T, false, 2>), gb, dim3(256), 0, G.stream, (const c2<T> *)zmid, zout, twL);
+        else if (R == 4) hipLaunchKernelGGL((big_fft_b<T, false, 4>), gb, dim3(256), 0, G.stream, (const c2<T> *)zmid, zout, twL);
+        else hipLaunchKernelGGL((big_fft_b<T, false, 8>), gb, dim3(256), 0, G.stream, (const c2<T> *)zmid, zout, twL);
+        hipLaunchKernelGGL(k_big_r2hc_post<T>, gh, dim3(256), 0, G.stream, (const c2<T> *)zout, (T *)out, twL, L);
+    }
+    return hipGetLastError() == hipSuccess;
+}
+
 // device-side real FFT of 2^(log2c+1) reals, buffers on the device
 bool dev_fft(int log2c, bool inverse, const void *in, void *out) {
+    if (log2c > BIG_LOG2M && log2c <= 16)
+        return G.rs == 4 ? big_fft_launch<float>(log2c, inverse, in, out) : big_fft_launch<double>(log2c, inverse, in, out);
 #define CASE(n) case n: if (G.rs == 4) fft_launch<float, n>(inverse, in, out); else fft_launch<double, n>(inverse, in, out); break;
     switch (log2c) {
         CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13)
@@ -497,7 +579,7 @@ int convolver_init(const char config_filename[], int length, int realsize) {
     int order = 0;
     while ((1 << order) < length) order++;
     if (length < 1 || (1 << order) != length) { fprintf(stderr, "Invalid length %d.\n", length); return 0; }
-    if (order > 13) { fprintf(stderr, "Invalid length %d (the device path supports up to 8192).\n", length); return 0; }
+    if (order > 16) { fprintf(stderr, "Invalid length %d (the device path supports up to 65536).\n", length); return 0; }
     G.L = length; G.rs = realsize; G.log2L = order; G.inited = true; G.last_fatal = 0;
     G.pid = 0;                                 /* device comes up lazily, per process */
     return 1;

@@ -92,8 +92,22 @@ def test_runtime_coefficient_update_at_65536(hip):
         assert cases.rel_rms(cases.samples(g, "FLOAT_LE"), cases.samples(o, "FLOAT_LE")) <= TOL[4], b
 
 
+@pytest.mark.parametrize("L", [4, 8, 16, 32])
+@pytest.mark.parametrize("rs", [4, 8])
+def test_tiny_partitions(hip, L, rs):
+    """the other end of the range: bfconf.c:1512-1514 allows any power of two with L * N >= 4"""
+    N, I, O = 5, 2, 3
+    coeffs = [(_ir(240 + k, L * N, I), 1.0, 0) for k in range(4)]
+    filters = [dict(in_ch=[0], out_ch=[0], coeff=0), dict(in_ch=[1], out_ch=[1], coeff=1, delayblocks=2),
+               dict(in_ch=[0, 1], in_scale=[0.5, -0.5], out_ch=[2], coeff=2),
+               dict(in_f=[0], in_ch=[1], out_ch=[2], coeff=3), dict(in_ch=[0], out_ch=[1], coeff=-1)]
+    _compare(hip, _spec(L, N, rs, I, O, filters, coeffs), 3 * N)
+
+
 def test_length_limits(hip):
     with pytest.raises(hip.BfhipError, match="Invalid length"):
         hip.Engine(131072, 1, 4, 1, 1)
     with pytest.raises(hip.BfhipError, match="Invalid length"):
-        hip.Engine(32, 4, 4, 1, 1)
+        hip.Engine(2, 4, 4, 1, 1)
+    with pytest.raises(hip.BfhipError, match="Invalid length"):
+        hip.Engine(96, 4, 4, 1, 1)
