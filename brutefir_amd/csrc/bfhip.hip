@@ -250,7 +250,8 @@ struct bfhip_engine {
     void *d_sdjobs[2] = {nullptr, nullptr};
 
     // HP-TPDF dither (dither.c, dither.h)
-    std::vector<int> dither_channels;      // output channel of each dither slot
+    std::vector<int> dither_channels;      // output channel of each dither slot (virtual, ascending, after finalize)
+    std::vector<int> dither_rank;          // its rank among the dithered PHYSICAL outputs: where its table walk starts
     std::vector<int8_t> dither_table;
     int dither_spacing = 0;
     int *d_dither_ch = nullptr;
@@ -1537,8 +1538,6 @@ int bfhip_engine_map_channels(bfhip_engine *e, int io, int n_phys, const int vir
     std::vector<int> cnt(n_phys, 0);
     for (int v = 0; v < e->n_ch[io]; v++) {
         if (virt2phys[v] < 0 || virt2phys[v] >= n_phys) return fail(BFHIP_EINVAL, "map_channels: physical channel %d", virt2phys[v]);
-        // bfrun.c:1981 counts the members of a physical output as they come: they must be adjacent
-        if (v > 0 && virt2phys[v] < virt2phys[v - 1]) return fail(BFHIP_EINVAL, "map_channels: virtual channels of a physical channel must be consecutive");
         cnt[virt2phys[v]]++;
     }
     for (int c = 0; c < n_phys; c++) if (cnt[c] == 0) return fail(BFHIP_EINVAL, "map_channels: physical channel %d unused", c);
@@ -1592,7 +1591,7 @@ int bfhip_engine_enable_dither(bfhip_engine *e, const int out_channels[], int n,
     if (e->finalized) return fail(BFHIP_ESTATE, "enable_dither after finalize");
     std::vector<int> chs(out_channels, out_channels + n);
     for (int i = 0; i < n; i++) {
-        if (chs[i] < 0 || chs[i] >= e->n_ch[1]) return fail(BFHIP_EINVAL, "enable_dither: output channel %d", chs[i]);
+        if (chs[i] < 0 || chs[i] >= e->n_phys[1]) return fail(BFHIP_EINVAL, "enable_dither: output channel %d", chs[i]);
         if (i > 0 && chs[i] <= chs[i - 1]) return fail(BFHIP_EINVAL, "enable_dither: channels must be ascending");
         if (e->fmt[1][chs[i]].isfloat) return fail(BFHIP_EINVAL, "cannot dither floating point format (output %d)", chs[i]);
     }
@@ -1646,15 +1645,10 @@ static int dither_upload(bfhip_engine *e) {
     // per-slot state: ptr = n*spacing + 1, error feedback zero (dither.c:133-137)
     const size_t ssz = e->rs == 4 ? sizeof(DitherState<float>) : sizeof(DitherState<double>);
     std::vector<unsigned char> stv(ssz * n, 0);
-    for (int i = 0; i < n; i++) *(int *)(stv.data() + ssz * i) = i * e->dither_spacing + 1;
+    for (int i = 0; i < n; i++) *(int *)(stv.data() + ssz * i) = e->dither_rank[i] * e->dither_spacing + 1;
     HIPCHK(hipMalloc(&e->d_dither_state, stv.size()));
     HIPCHK(hipMemcpy(e->d_dither_state, stv.data(), stv.size(), hipMemcpyHostToDevice));
-    std::vector<unsigned char> skip(e->n_ch[1], 0);
-    for (int c : e->dither_channels) skip[c] = 1;
-    HIPCHK(hipMalloc((void **)&e->d_skip_quant, skip.size()));
-    HIPCHK(hipMemcpy(e->d_skip_quant, skip.data(), skip.size(), hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc(&e->d_timeout, (size_t)e->n_ch[1] * e->L * e->rs));
-    return BFHIP_OK;
+    return BFHIP_OK;             // d_skip_quant / d_timeout: allocated with the channel set-up in finalize
 }
 
 static int add_coeff_common(bfhip_engine *e, const void *taps, bool on_device, int n_taps,
@@ -1850,18 +1844,38 @@ int bfhip_engine_finalize(bfhip_engine *e) {
     {
         e->vin_list.clear(); e->vout_groups.clear();
         for (int v = 0; v < e->n_ch[0]; v++) if (e->n_vpp[0][e->v2p[0][v]] > 1) e->vin_list.push_back(v);
+        // the members of a shared physical output are mixed in ascending virtual order, the order
+        // in which the reference walks phys2virt (bfrun.c:2322-2323, 1938-2003); any mapping is
+        // legal (bench4_config: `mapping: 0,1,0,1,0,1`)
+        std::map<int, std::vector<int>> shared;
         for (int v = 0; v < e->n_ch[1]; v++) {
             if (e->n_vpp[1][e->v2p[1][v]] <= 1) {
                 // a 1:1 output with a sub-sample filter is requantised after the filter: a group of one
                 if (e->sd_slot[1][v] >= 0) e->vout_groups.push_back({v});
                 continue;
             }
-            if (e->vout_groups.empty() || e->v2p[1][e->vout_groups.back()[0]] != e->v2p[1][v]) e->vout_groups.push_back({});
-            e->vout_groups.back().push_back(v);
+            shared[e->v2p[1][v]].push_back(v);
         }
+        for (auto &kv : shared) e->vout_groups.push_back(kv.second);
         e->has_vchan = !e->vin_list.empty() || !e->vout_groups.empty() || e->sdf_length > 0;
+        // enable_dither named PHYSICAL outputs (bfconf->dither_state[physch], bfrun.c:1933): from
+        // here on the list holds the virtual channel behind each of them
+        {
+            std::vector<std::pair<int, int>> byvirt;            // (virtual channel, rank in the physical list)
+            for (size_t i = 0; i < e->dither_channels.size(); i++) {
+                const int c = e->dither_channels[i];
+                if (c < 0 || c >= e->n_phys[1]) return fail(BFHIP_EINVAL, "dither: output %d does not exist", c);
+                if (e->n_vpp[1][c] != 1) return fail(BFHIP_EINVAL, "dither on outputs that share a physical channel is not supported");
+                int v = 0;
+                while (e->v2p[1][v] != c) v++;
+                if (e->sd_slot[1][v] >= 0) return fail(BFHIP_EINVAL, "dither on an output with a sub-sample delay filter is not supported");
+                byvirt.push_back({v, (int)i});
+            }
+            std::sort(byvirt.begin(), byvirt.end());
+            e->dither_rank.clear();
+            for (size_t j = 0; j < byvirt.size(); j++) { e->dither_channels[j] = byvirt[j].first; e->dither_rank.push_back(byvirt[j].second); }
+        }
         if (e->has_vchan) {
-            if (!e->dither_channels.empty()) return fail(BFHIP_EINVAL, "dither on outputs that share a physical channel is not supported");
             size_t n_ops_max = 0;
             e->vline[0].assign(e->n_ch[0], DelayLine());
             e->vline[1].assign(e->n_ch[1], DelayLine());
@@ -1885,14 +1899,17 @@ int bfhip_engine_finalize(bfhip_engine *e) {
             e->vjobs_slot = (n_ops_max + 8) * sizeof(ByteOp) + (e->n_ch[0] + e->n_ch[1] + 8) * 64;
             HIPCHK(hipMalloc(&e->d_vjobs, 2 * e->vjobs_slot));
             e->vline[0].resize(e->n_ch[0]); e->vline[1].resize(e->n_ch[1]);
-            if (!e->vout_groups.empty()) {
-                std::vector<unsigned char> skip(e->n_ch[1], 0);
-                for (auto &g : e->vout_groups) for (int v : g) skip[v] = 1;
-                HIPCHK(hipMalloc((void **)&e->d_skip_quant, skip.size()));
-                HIPCHK(hipMemcpy(e->d_skip_quant, skip.data(), skip.size(), hipMemcpyHostToDevice));
-                HIPCHK(hipMalloc(&e->d_timeout, (size_t)e->n_ch[1] * e->L * e->rs));
-                HIPCHK(hipMemset(e->d_timeout, 0, (size_t)e->n_ch[1] * e->L * e->rs));
-            }
+        }
+        // outputs K3 does not requantise itself (the dither pass or the N:1 mix does, from the time
+        // samples K3 leaves in d_timeout)
+        if (!e->vout_groups.empty() || !e->dither_channels.empty()) {
+            std::vector<unsigned char> skip(e->n_ch[1], 0);
+            for (auto &g : e->vout_groups) for (int v : g) skip[v] = 1;
+            for (int c : e->dither_channels) skip[c] = 1;
+            HIPCHK(hipMalloc((void **)&e->d_skip_quant, skip.size()));
+            HIPCHK(hipMemcpy(e->d_skip_quant, skip.data(), skip.size(), hipMemcpyHostToDevice));
+            HIPCHK(hipMalloc(&e->d_timeout, (size_t)e->n_ch[1] * e->L * e->rs));
+            HIPCHK(hipMemset(e->d_timeout, 0, (size_t)e->n_ch[1] * e->L * e->rs));
         }
     }
     int r = upload_formats(e);

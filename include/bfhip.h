@@ -93,8 +93,8 @@ void bfhip_engine_destroy(bfhip_engine *e);
 /* dai_buffer_format[io]->bf[channel] (dai.c:537-576); 1:1 virtual:physical channels */
 int bfhip_engine_set_format(bfhip_engine *e, int io, int channel, const bfhip_format *bf);
 /* N:1 virtual -> physical channel mapping (`mapping:` in an input/output device section,
-   bfconf->virt2phys / n_virtperphys).  The virtual channels of one physical channel must be
-   consecutive.  After this call bfhip_engine_set_format addresses PHYSICAL channels.  For
+   bfconf->virt2phys / n_virtperphys).  Any mapping is legal (bench4_config: 0,1,0,1,0,1); the
+   members of a shared physical output are mixed in ascending virtual order.  After this call bfhip_engine_set_format addresses PHYSICAL channels.  For
    channels that share a physical one, integer delay and mute happen inside the block like in
    filter_process() (bfrun.c:1509-1531, 1938-2003; delay.c) -- set them with the calls below at
    any time (what bfaccess->set_delay / toggle_mute write into icomm).  For 1:1 channels delay and

@@ -824,9 +824,6 @@ bfo_engine_map_channels(bfo_engine *e, int io, int n_phys, const int virt2phys[]
     for (v = 0; v < n_phys; v++) e->n_vpp[io][v] = 0;
     for (v = 0; v < e->n_ch[io]; v++) {
         if (virt2phys[v] < 0 || virt2phys[v] >= n_phys) return 0;
-        /* the virtual channels of one physical channel are consecutive (bfrun.c:1981 counts
-           them as they come) */
-        if (v > 0 && virt2phys[v] < virt2phys[v - 1]) return 0;
         e->v2p[io][v] = virt2phys[v];
         e->n_vpp[io][virt2phys[v]]++;
     }
@@ -1088,11 +1085,19 @@ bfo_engine_block(bfo_engine *e, const void *rawin, void *rawout)
 
     /* :1847-1868 output mix, then :1877-2003 inverse FFT, (delay / mute / N:1 mix), quantise */
     {
-        int filled = 0, seen = 0;
-        for (n = 0; n < e->n_ch[1]; n++) {
+        int filled = 0, seen = 0, idx;
+        /* the process's output list is built physical channel by physical channel, members in
+           phys2virt order (bfrun.c:2322-2323); :1981 counts the members as they come */
+        int order[e->n_ch[1]];
+        {
+            int ph2, k = 0;
+            for (ph2 = 0; ph2 < e->n_phys[1]; ph2++)
+                for (n = 0; n < e->n_ch[1]; n++) if (e->v2p[1][n] == ph2) order[k++] = n;
+        }
+        for (idx = 0; idx < e->n_ch[1]; idx++) {
             void *src[e->n_filters > 0 ? e->n_filters : 1];
             double scales[e->n_filters > 0 ? e->n_filters : 1];
-            const int ph = e->v2p[1][n];
+            const int ph = e->v2p[1][(n = order[idx])];
             const bfo_format *bf = &e->fmt[1][ph];
             int cnt = 0, j, r = 0;
             for (i = 0; i < e->n_filters; i++) {

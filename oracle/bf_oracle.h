@@ -117,7 +117,8 @@ void bfo_engine_set_safety_limit(bfo_engine *e, double limit);
 int bfo_engine_enable_dither(bfo_engine *e, const int out_channels[], int n,
                              int sample_rate, int max_size);
 /* N:1 virtual -> physical channel mapping (`mapping:` in the config; bfconf->virt2phys).
-   Virtual channels of one physical channel must be consecutive.  After this call
+   Any mapping is legal (bench4_config: `mapping: 0,1,0,1,0,1`); outputs are processed grouped by
+   physical channel, members in ascending virtual order (bfrun.c:2322-2323).  After this call
    set_format / enable_dither address PHYSICAL channels.  For channels that share a physical
    one, integer delay and mute are applied inside the block (bfrun.c:1509-1531,1938-2003);
    for 1:1 channels they are dai.c's business and ignored here.  Returns 1 / 0. */

@@ -124,6 +124,8 @@ def _vchan_case(seed):
         v2p = []
         for p in range(n_phys):
             v2p += [p] * int(rng.integers(1, 4))
+        if rng.random() < 0.5:                       # any mapping is legal (bench4_config: 0,1,0,1,0,1)
+            v2p = [int(x) for x in rng.permutation(v2p)]
         maps.append(v2p)
         nv.append(len(v2p))
     infmt = str(rng.choice(["S16_LE", "S32_LE", "S24_4LE", "FLOAT_LE"]))
