@@ -14,16 +14,17 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_c_host_file_to_file(hip, tmp_path):
+@pytest.mark.parametrize("L,N", [(512, 4), (65536, 1)])
+def test_c_host_file_to_file(hip, tmp_path, L, N):
     exe = os.path.join(ROOT, "examples", "bffilter")
     subprocess.check_call(["gcc", "-std=c99", "-O2", "-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "examples", "bffilter.c"), "-o", exe,
                            "-L" + os.path.join(ROOT, "brutefir_amd"), "-lbfhip",
                            "-Wl,-rpath," + os.path.join(ROOT, "brutefir_amd")])
-    L, N, I, O = 512, 4, 2, 3
+    I, O = 2, 3                                  # (65536, 1): the stock `filter_length: 65536;`
     irs = np.stack([cases.make_ir(np.random.default_rng(100 + k), L * N, I) for k in range(O * I)])
     irs.astype(np.float32).tofile(tmp_path / "coeffs.f32")
-    nblk = 9
+    nblk = 9 if L < 4096 else 3
     blocks = cases.raw_blocks(42, nblk, L, I, "S16_LE", amplitude=0.2)
     raw = np.concatenate(blocks)[:nblk * L - 100]                   # a ragged last block
     raw.tofile(tmp_path / "in.raw")
