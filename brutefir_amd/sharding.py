@@ -48,3 +48,48 @@ def mixdown(z_partial, z_local, group=None):
     else:
         dist.reduce_scatter_tensor(z_local, z_partial, group=group)
     return z_local
+
+
+def load_balance_filters(filters, n_ranks):
+    """The reference's own partition of a filter network (bfconf.c:2227-2318): filters that are
+    connected through from_filters / to_filters, or that mix into the same output, must share a
+    process; the groups that remain are dealt round-robin over the processes.  Groups built this
+    way need NO exchange at all -- every output is finished where it is computed -- so for
+    configurations like massive_config (independent channels) each GPU simply runs its groups
+    with an engine of its own.  (A full crossbar is a single group under this rule; that is the
+    case `shard_crossbar` + `mixdown` exist for.)
+
+    filters: list of dicts with optional keys in_f (indices of source filters) and out_ch.
+    Returns (rank of every filter, number of ranks actually used)."""
+    n = len(filters)
+    proc = [-1] * n
+    links = [set(f.get("in_f", ())) for f in filters]
+    for i, f in enumerate(filters):                       # to_filters is the same edge seen from the source
+        for g in f.get("in_f", ()):
+            links[g].add(i)
+    process = 0
+    for first in range(n):
+        if proc[first] != -1:
+            continue
+        proc[first] = process
+        changed = True
+        while changed:
+            changed = False
+            for i in range(n):
+                if proc[i] != process:
+                    continue
+                for k in links[i]:
+                    if proc[k] != process:
+                        proc[k] = process
+                        changed = True
+            used = set()
+            for i in range(n):
+                if proc[i] == process:
+                    used.update(filters[i].get("out_ch", ()))
+            for i in range(n):
+                if proc[i] != process and used.intersection(filters[i].get("out_ch", ())):
+                    proc[i] = process
+                    changed = True
+        process += 1
+    ranks = [p % n_ranks for p in proc]
+    return ranks, min(process, n_ranks)

@@ -84,3 +84,21 @@ def test_shard_arithmetic():
     assert sharding.shard_crossbar(64, 64, 1, 0) == (0, 64, 0, 64)
     with pytest.raises(ValueError):
         sharding.shard_crossbar(26, 26, 8, 0)
+
+
+def test_load_balance_follows_the_reference_rules():
+    """bfconf.c:2227-2318 on the shipped configurations"""
+    from brutefir_amd.sharding import load_balance_filters
+    # bench1_config: everything is connected through from_filters -> one process
+    bench1 = [dict(in_f=[2, 5], out_ch=[0]), dict(in_f=[3, 4], out_ch=[1]), dict(), dict(), dict(), dict()]
+    assert load_balance_filters(bench1, 8) == ([0] * 6, 1)
+    # massive_config: 26 independent channels -> round robin
+    massive = [dict(out_ch=[i]) for i in range(26)]
+    ranks, used = load_balance_filters(massive, 8)
+    assert used == 8 and ranks == [i % 8 for i in range(26)]
+    # a crossbar mixes into shared outputs -> one group (the case the reduce-scatter path is for)
+    xbar = [dict(out_ch=[o]) for o in range(4) for _ in range(4)]
+    assert load_balance_filters(xbar, 8) == ([0] * 16, 1)
+    # two islands: {0 -> 2} share nothing with {1, 3 mixing into output 5}
+    isl = [dict(out_ch=[0]), dict(out_ch=[5]), dict(in_f=[0], out_ch=[1]), dict(out_ch=[5, 6])]
+    assert load_balance_filters(isl, 2) == ([0, 1, 0, 1], 2)
