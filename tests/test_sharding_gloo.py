@@ -89,9 +89,9 @@ def test_shard_arithmetic():
 def test_load_balance_follows_the_reference_rules():
     """bfconf.c:2227-2318 on the shipped configurations"""
     from brutefir_amd.sharding import load_balance_filters
-    # bench1_config: everything is connected through from_filters -> one process
+    # bench1_config: two cascades {0 <- 2, 5} and {1 <- 3, 4} that share inputs only -> two processes
     bench1 = [dict(in_f=[2, 5], out_ch=[0]), dict(in_f=[3, 4], out_ch=[1]), dict(), dict(), dict(), dict()]
-    assert load_balance_filters(bench1, 8) == ([0] * 6, 1)
+    assert load_balance_filters(bench1, 8) == ([0, 1, 0, 1, 1, 0], 2)
     # massive_config: 26 independent channels -> round robin
     massive = [dict(out_ch=[i]) for i in range(26)]
     ranks, used = load_balance_filters(massive, 8)
