@@ -54,10 +54,12 @@ def load_balance_filters(filters, n_ranks):
     """The reference's own partition of a filter network (bfconf.c:2227-2318): filters that are
     connected through from_filters / to_filters, or that mix into the same output, must share a
     process; the groups that remain are dealt round-robin over the processes.  Groups built this
-    way need NO exchange at all -- every output is finished where it is computed -- so for
+    way never exchange OUTPUT data -- every output is finished where it is computed.  For
     configurations like massive_config (independent channels) each GPU simply runs its groups
-    with an engine of its own.  (A full crossbar is a single group under this rule; that is the
-    case `shard_crossbar` + `mixdown` exist for.)
+    with an engine of its own; a crossbar falls apart by output channel, and every process then
+    needs the spectra of ALL inputs (shared memory in the reference; an all-gather of input
+    spectra between GPUs).  `shard_crossbar` + `mixdown` split by input instead: each GPU
+    transforms only its own inputs and one reduce-scatter finishes the outputs.
 
     filters: list of dicts with optional keys in_f (indices of source filters) and out_ch.
     Returns (rank of every filter, number of ranks actually used)."""

@@ -96,9 +96,10 @@ def test_load_balance_follows_the_reference_rules():
     massive = [dict(out_ch=[i]) for i in range(26)]
     ranks, used = load_balance_filters(massive, 8)
     assert used == 8 and ranks == [i % 8 for i in range(26)]
-    # a crossbar mixes into shared outputs -> one group (the case the reduce-scatter path is for)
+    # a crossbar splits by OUTPUT: the filters that mix into one output stay together, every
+    # process reads all input spectra (the all-gather variant of SURVEY 8e)
     xbar = [dict(out_ch=[o]) for o in range(4) for _ in range(4)]
-    assert load_balance_filters(xbar, 8) == ([0] * 16, 1)
+    assert load_balance_filters(xbar, 8) == ([o for o in range(4) for _ in range(4)], 4)
     # two islands: {0 -> 2} share nothing with {1, 3 mixing into output 5}
     isl = [dict(out_ch=[0]), dict(out_ch=[5]), dict(in_f=[0], out_ch=[1]), dict(out_ch=[5, 6])]
     assert load_balance_filters(isl, 2) == ([0, 1, 0, 1], 2)
