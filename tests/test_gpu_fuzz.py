@@ -262,3 +262,122 @@ def test_random_nonuniform_schedules_equal_the_uniform_convolution(hip, seed):
             err = float(np.sqrt(((gs[:, ch] - os_[:, ch]) ** 2).mean()))
             lvl = max(float(np.sqrt((os_[:, ch] ** 2).mean())), FLOOR)
             assert err <= tol * lvl, (seed, b, ch, err, lvl, seg_len, seg_blk)
+
+
+ALL_FORMATS = ["S8", "S16_LE", "S16_BE", "S24_LE", "S24_BE", "S24_4LE", "S24_4BE", "S32_LE", "S32_BE",
+               "FLOAT_LE", "FLOAT_BE", "FLOAT64_LE", "FLOAT64_BE"]
+BITS = {"S8": 8, "S16": 16, "S24": 24, "S32": 32}
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("BFHIP_FUZZ_SEEDS", "60"))))
+def test_random_sample_formats_dither_and_subsample_delays(hip, seed):
+    """every channel its own sample format (all 13, both byte orders, packed 24 bit), interleaved
+    in one frame with unused gaps; HP-TPDF dither on a random subset of the integer outputs;
+    sub-sample delays on a random subset of inputs and outputs, changed at run time.  Quantised
+    outputs: float64 engines within 1 LSB (exact ties), float32 within its rounding noise."""
+    rng = np.random.default_rng(7000 + seed)
+    L = int(rng.choice([128, 256, 512]))
+    N = int(rng.integers(1, 5))
+    rs = int(rng.choice([4, 8]))
+    n_in, n_out = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+    fmts = [[str(rng.choice(ALL_FORMATS)) for _ in range(n)] for n in (n_in, n_out)]
+    use_sd = bool(rng.random() < 0.4)
+    layout, nbytes = [[], []], [0, 0]
+    for io in range(2):
+        # one device per channel format would need equal sample sizes inside a frame; instead
+        # every channel is its own single-channel "device" region, placed one after the other
+        off = 0
+        for name in fmts[io]:
+            b = bo.SAMPLE_FORMATS[name][0]
+            layout[io].append((name, 1, off))
+            off += b * L + int(rng.integers(0, 3)) * 8            # a gap nobody owns
+        nbytes[io] = off
+    coeffs = [cases.make_ir(rng, L * N, n_in) for _ in range(2)]
+    filters = []
+    for o in range(n_out):
+        for i in range(n_in):
+            if rng.random() < 0.7 or (i == 0 and not any(o in f["out_ch"] for f in filters)):
+                filters.append(dict(in_ch=[i], out_ch=[o], coeff=int(rng.integers(-1, 2)),
+                                    out_scale=[float(rng.choice([1.0, -0.5, 2.0]))]))
+    dither = [o for o in range(n_out) if not fmts[1][o].startswith("FLOAT") and rng.random() < 0.5]
+    sd = [[int(rng.integers(-99, 100)) if use_sd and rng.random() < 0.5 else None for _ in range(n)] for n in (n_in, n_out)]
+    dither = [o for o in dither if sd[1][o] is None]              # not supported together (documented)
+    half = int(rng.choice([7, 15, 31]))
+
+    def mk(mod):
+        e = mod.Engine(L, N, rs, n_in, n_out)
+        for io in range(2):
+            for c, (name, spacing, off) in enumerate(layout[io]):
+                e.set_format(io, c, mod.make_format(name, spacing, off))
+        e.in_bytes, e.out_bytes = nbytes
+        if use_sd:
+            e.enable_subdelay(half)
+            for io in range(2):
+                for c, v in enumerate(sd[io]):
+                    if v is not None:
+                        e.set_subdelay(io, c, v)
+        for h in coeffs:
+            e.add_coeff(h)
+        if dither:
+            e.enable_dither(dither, 44100, 0)
+        for f in filters:
+            e.add_filter(**f)
+        if hasattr(e, "finalize"):
+            e.finalize()
+        return e
+    ge, oe = mk(hip), mk(bo)
+    n_blocks = 2 * N + 5
+    for b in range(n_blocks):
+        buf = np.zeros(nbytes[0], np.uint8)
+        for name, spacing, off in layout[0]:
+            nb, sb, isf, le = bo.SAMPLE_FORMATS[name]
+            x = rng.standard_normal(L) * 0.15
+            if isf:
+                raw = x.astype(np.float32 if nb == 4 else np.float64).view(np.uint8).reshape(L, nb)
+            else:
+                bits = 8 * sb
+                q = np.clip(np.round(x * (1 << (bits - 1))), -(1 << (bits - 1)), (1 << (bits - 1)) - 1).astype(np.int64)
+                raw = np.stack([(q >> (8 * k)) & 0xff for k in range(nb)], axis=1).astype(np.uint8)
+            if not le:
+                raw = raw[:, ::-1]
+            buf[off + np.arange(L)[:, None] * nb + np.arange(nb)[None, :]] = raw
+        if use_sd and b == N + 2:
+            for eng in (ge, oe):
+                for io in range(2):
+                    for c, v in enumerate(sd[io]):
+                        if v is not None:
+                            eng.set_subdelay(io, c, int((v + 37) % 199 - 99))
+        gs, g = ge.block(buf)
+        os_, o = oe.block(buf)
+        assert gs == os_, (seed, b)
+        for ch, (name, spacing, off) in enumerate(layout[1]):
+            nb, sb, isf, le = bo.SAMPLE_FORMATS[name]
+            idx = off + np.arange(L)[:, None] * nb + np.arange(nb)[None, :]
+            gr, orr = g[idx], o[idx]
+            if not le:
+                gr, orr = gr[:, ::-1], orr[:, ::-1]
+            if isf:
+                dt = np.float32 if nb == 4 else np.float64
+                gv = np.ascontiguousarray(gr).view(dt).ravel().astype(np.float64)
+                ov = np.ascontiguousarray(orr).view(dt).ravel().astype(np.float64)
+                lvl = max(float(np.sqrt((ov ** 2).mean())), FLOOR)
+                tol = (3e-5 if rs == 4 else 1e-11)
+                if nb == 4:
+                    tol = max(tol, 1e-7)             # stored as float32: one ulp on ties
+                assert float(np.sqrt(((gv - ov) ** 2).mean())) <= tol * lvl, (seed, b, ch, name)
+            else:
+                def dec(r):
+                    v = np.zeros(L, np.int64)
+                    for k in range(sb):
+                        v |= r[:, k].astype(np.int64) << (8 * k)
+                    return np.where(v >= (1 << (8 * sb - 1)), v - (1 << (8 * sb)), v)
+                d = np.abs(dec(gr) - dec(orr)).max()
+                # float64: the pre-quantiser values agree to ~1e-12, so the integers agree except
+                # on exact ties (a dirac path scaled by 0.5 lands ON .5): 1 LSB.  float32 carries
+                # 24 bits: 2 LSB (rounding flip + the dither quantiser's feedback) plus its own
+                # rounding noise, which scales with the level (3e-6 of the block's peak).
+                lim = 1 if rs == 8 else 2 + 3e-6 * float(np.abs(dec(orr)).max())
+                assert d <= lim, (seed, b, ch, name, int(d), lim)
+    for ch in range(n_out):
+        a, c = ge.overflow(ch), oe.overflow(ch)
+        assert a.n_overflows == c.n_overflows and a.max == c.max, (seed, ch)
