@@ -315,7 +315,7 @@ def main():
     if world == 1:
         # per-kernel HIP events on every 4th block of the timed region: the records themselves
         # cost the stream ~20 us per block, which would otherwise be charged to `value`
-        eng.enable_timing(0 if os.environ.get("BFHIP_BENCH_NO_EVENTS") else 4)
+        eng.enable_timing(0 if os.environ.get("BFHIP_BENCH_NO_EVENTS") else (4 if args.steps >= 32 else 1))
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(args.warmup + k)
