@@ -1199,6 +1199,16 @@ int do_outputs(bfhip_engine *e, const void *Zp, size_t chunk_stride, int n_chunk
     if (count <= 0) return BFHIP_OK;
     if (!e->vout_groups.empty() && (first != 0 || count != e->n_ch[1]))
         return fail(BFHIP_EINVAL, "outputs that share a physical channel cannot be split over several calls");
+    if (n_chunks > 2 && n_chunks == e->n_chunks && first == 0 && count == e->n_ch[1] &&
+        chunk_stride == (size_t)e->n_out_padded * e->L) {
+        // many partials (few long filters): the one-workgroup-per-channel output pass would walk
+        // them one dependent load after the other; add them up with the whole chip first
+        // (in place, same order) and hand over a single spectrum per channel
+        if (e->rs == 4) launch_sum<float>(e, Zp, const_cast<void *>(Zp), &err);
+        else launch_sum<double>(e, Zp, const_cast<void *>(Zp), &err);
+        if (err != hipSuccess) return fail(BFHIP_EHIP, "sum_partials launch: %s", hipGetErrorString(err));
+        n_chunks = 1;
+    }
     if (e->big) { int rr = big_reserve(e, (size_t)count); if (rr != BFHIP_OK) return rr; }
     if (e->big) DISPATCH_BIG(launch_ifft_out_big, e, Zp, chunk_stride, n_chunks, first, count, (uint8_t *)rawout_dev, &err);
     else DISPATCH(launch_ifft_out, e, Zp, chunk_stride, n_chunks, first, count, (uint8_t *)rawout_dev, &err);

@@ -105,9 +105,16 @@ constexpr int tw_total(int log2l, int nt, int log2ns) {
 // 2L + q*NT + tid is register q of thread tid -- so that a wave fetches each register with one
 // contiguous 512-byte load instead of a 64-line gather (the gathers of 16 waves kept the CU's
 // texture path busy for ~3 us of a 17 us transform at L = 8192).
+// LAZY (float64 at L = 8192: 32 twiddles = 128 VGPRs, which made the kernels spill): nothing is
+// held in registers, every pass reads its twiddles from the thread-ordered table when it needs
+// them -- still one coalesced load per value.
 template <typename T, int LOG2L, int NT> struct TwRegs {
-    static constexpr int N = tw_total(LOG2L, NT, 0) > 0 ? tw_total(LOG2L, NT, 0) : 1;
+    static constexpr bool LAZY = sizeof(T) == 8 && LOG2L >= 13;
+    static constexpr int N = (LAZY || tw_total(LOG2L, NT, 0) == 0) ? 1 : tw_total(LOG2L, NT, 0);
     c2<T> r[N];
+    const c2<T> *g;                 // thread-ordered table, this thread's column
+
+    __device__ __forceinline__ c2<T> get(int q) const { return LAZY ? g[q * NT] : r[q]; }
 
     template <int LOG2NS, int OFF>
     __device__ __forceinline__ void fetch_from(const c2<T> *__restrict__ tw) {
@@ -127,7 +134,10 @@ template <typename T, int LOG2L, int NT> struct TwRegs {
             fetch_from<LOG2NS + LOG2R, OFF + B * NTW>(tw);
         }
     }
-    __device__ __forceinline__ void prefetch(const c2<T> *__restrict__ tw) { fetch_from<0, 0>(tw); }
+    __device__ __forceinline__ void prefetch(const c2<T> *__restrict__ tw) {
+        g = tw + 2 * (1 << LOG2L) + (int)threadIdx.x;
+        if constexpr (!LAZY) fetch_from<0, 0>(tw);
+    }
 };
 
 // one Stockham pass on the padded LDS array with prefetched twiddles
@@ -146,15 +156,15 @@ __device__ __forceinline__ void fft_pass(LdsArr<T> s, const TwRegs<T, LOG2L, NT>
             for (int r = 0; r < R; r++) u[b][r] = s[j + r * TT];
             if constexpr (NTW > 0) {
                 c2<T> w[R];
-                w[1] = tw.r[OFF + b * NTW];
+                w[1] = tw.get(OFF + b * NTW);
                 if (INV) w[1].y = -w[1].y;
                 if constexpr (R >= 4) {
-                    w[2] = tw.r[OFF + b * NTW + 1];
+                    w[2] = tw.get(OFF + b * NTW + 1);
                     if (INV) w[2].y = -w[2].y;
                     w[3] = cmul(w[1], w[2]);
                 }
                 if constexpr (R == 8) {
-                    w[4] = tw.r[OFF + b * NTW + 2];
+                    w[4] = tw.get(OFF + b * NTW + 2);
                     if (INV) w[4].y = -w[4].y;
                     w[5] = cmul(w[4], w[1]); w[6] = cmul(w[4], w[2]); w[7] = cmul(w[4], w[3]);
                 }

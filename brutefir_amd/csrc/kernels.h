@@ -654,7 +654,7 @@ mac_xbar_kernel(const MacEntry<T> *__restrict__ entries, const ChunkRange *__res
 // Z[o][k] = sum_c Zp[c][o][k]   (only used when the spectra leave the engine: multi-GPU)
 template <typename T>
 __global__ __launch_bounds__(256) void
-sum_partials_kernel(const c2<T> *__restrict__ Zp, c2<T> *__restrict__ Z, size_t n_per_chunk,
+sum_partials_kernel(const c2<T> *Zp, c2<T> *Z /* may be Zp: in place */, size_t n_per_chunk,
                     size_t n_valid, int n_chunks) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_valid) return;
@@ -997,7 +997,10 @@ ifft_out_body(int zi /* index into Zp's channel axis */, unsigned char *smem,
         if (k <= L / 2) { za[i] = z[k]; zb[i] = z[L - k]; }
     }
     if (tid == 0) z0 = z[0];
-    if (n_chunks > 1) {
+    // the second chunk rides along only where the registers allow it (8 bins per thread in
+    // float64 at L = 8192 would spill)
+    constexpr bool PRELOAD2 = QU * sizeof(c2<T>) <= 64;
+    if (PRELOAD2 && n_chunks > 1) {
         const c2<T> *zc = z + chunk_stride;
 #pragma unroll
         for (int i = 0; i < QU; i++) {
@@ -1014,12 +1017,12 @@ ifft_out_body(int zi /* index into Zp's channel axis */, unsigned char *smem,
     DevOverflow of = over[ch];
     const bool quant = skip_quant == nullptr || !skip_quant[ch];
     // chunk partials add up in chunk order (deterministic)
-    if (n_chunks > 1) {
+    if (PRELOAD2 && n_chunks > 1) {
         z0 = z0 + t0;
 #pragma unroll
         for (int i = 0; i < QU; i++) { za[i] = za[i] + ta[i]; zb[i] = zb[i] + tb[i]; }
     }
-    for (int c = 2; c < n_chunks; c++) {
+    for (int c = PRELOAD2 ? 2 : 1; c < n_chunks; c++) {
         const c2<T> *zc = z + (size_t)c * chunk_stride;
 #pragma unroll
         for (int i = 0; i < QU; i++) {
