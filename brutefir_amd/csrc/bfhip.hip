@@ -189,6 +189,10 @@ struct bfhip_engine {
     void *d_big[3] = {nullptr, nullptr, nullptr};   // zin, zmid, zout
     size_t big_cap = 0;            // transforms the scratch holds
     void *d_tw13 = nullptr;        // twiddle table of the 8192-point LDS transform
+    // K1/K3 in 256-thread workgroups (L = 8192): slow, but small enough to sit on a CU beside a MAC
+    // workgroup, so that the side streams of the pipelined block do not displace MAC workgroups
+    bool lowfoot = false;          // used for launches that go to the side streams only
+    void *d_tw_lo = nullptr;
 
     // device state
     void *d_tw = nullptr;          // [2L] complex
@@ -367,6 +371,20 @@ void launch_fft_in(bfhip_engine *e, const uint8_t *raw, int slot, hipError_t *er
     *err = hipGetLastError();
 }
 
+constexpr int LO_NT = 256;
+
+template <typename T>
+void launch_fft_in_lo(bfhip_engine *e, const uint8_t *raw, int slot, hipError_t *err) {
+    const size_t lds = lds_fft_bytes(13, sizeof(c2<T>));
+    auto k = fft_in_kernel<T, 13, LO_NT>;
+    *err = allow_lds(k, lds);
+    if (*err != hipSuccess) return;
+    hipLaunchKernelGGL(k, dim3(e->n_ch[0]), dim3(LO_NT), lds, e->ls, raw, e->d_fmt[0],
+                       (T *)e->d_prev, (c2<T> *)e->d_ring, (const c2<T> *)e->d_tw_lo, e->R, slot,
+                       (const BlockState *)e->bs_arg);
+    *err = hipGetLastError();
+}
+
 template <typename T, int LOG2L>
 void launch_coeff_prep(bfhip_engine *e, const void *taps, int n_taps, double scale, void *H,
                        int n_blocks, hipError_t *err) {
@@ -412,6 +430,22 @@ void launch_ifft_out(bfhip_engine *e, const void *Zp, size_t chunk_stride, int n
                        n_chunks, first, e->d_fmt[1], e->d_over, (const unsigned char *)e->d_skip_quant,
                        raw, e->d_timeout ? (T *)e->d_timeout + (size_t)first * e->L : (T *)nullptr,
                        (const c2<T> *)e->d_tw, e->safety_limit, e->d_status);
+    *err = hipGetLastError();
+    if (*err != hipSuccess) return;
+    launch_dither<T>(e, first, count, raw, err);
+}
+
+template <typename T>
+void launch_ifft_out_lo(bfhip_engine *e, const void *Zp, size_t chunk_stride, int n_chunks,
+                        int first, int count, uint8_t *raw, hipError_t *err) {
+    const size_t lds = lds_fft_bytes(13, sizeof(c2<T>));
+    auto k = ifft_out_kernel<T, 13, LO_NT>;
+    *err = allow_lds(k, lds);
+    if (*err != hipSuccess) return;
+    hipLaunchKernelGGL(k, dim3(count), dim3(LO_NT), lds, e->ls, (const c2<T> *)Zp, chunk_stride,
+                       n_chunks, first, e->d_fmt[1], e->d_over, (const unsigned char *)e->d_skip_quant,
+                       raw, e->d_timeout ? (T *)e->d_timeout + (size_t)first * e->L : (T *)nullptr,
+                       (const c2<T> *)e->d_tw_lo, e->safety_limit, e->d_status);
     *err = hipGetLastError();
     if (*err != hipSuccess) return;
     launch_dither<T>(e, first, count, raw, err);
@@ -1164,6 +1198,7 @@ int do_inputs(bfhip_engine *e, const void *rawin_dev) {
     const int slot = (int)(e->blockcounter % (unsigned int)e->R);
     if (e->big) { int rr = big_reserve(e, (size_t)e->n_ch[0]); if (rr != BFHIP_OK) return rr; }
     if (e->big) DISPATCH_BIG(launch_fft_in_big, e, (const uint8_t *)rawin_dev, slot, &err);
+    else if (e->lowfoot && e->ls != e->stream) DISPATCH_BIG(launch_fft_in_lo, e, (const uint8_t *)rawin_dev, slot, &err);
     else DISPATCH(launch_fft_in, e, (const uint8_t *)rawin_dev, slot, &err);
     if (err != hipSuccess) return fail(BFHIP_EHIP, "fft_in launch: %s", hipGetErrorString(err));
     return BFHIP_OK;
@@ -1211,6 +1246,7 @@ int do_outputs(bfhip_engine *e, const void *Zp, size_t chunk_stride, int n_chunk
     }
     if (e->big) { int rr = big_reserve(e, (size_t)count); if (rr != BFHIP_OK) return rr; }
     if (e->big) DISPATCH_BIG(launch_ifft_out_big, e, Zp, chunk_stride, n_chunks, first, count, (uint8_t *)rawout_dev, &err);
+    else if (e->lowfoot && e->ls != e->stream) DISPATCH_BIG(launch_ifft_out_lo, e, Zp, chunk_stride, n_chunks, first, count, (uint8_t *)rawout_dev, &err);
     else DISPATCH(launch_ifft_out, e, Zp, chunk_stride, n_chunks, first, count, (uint8_t *)rawout_dev, &err);
     if (err != hipSuccess) return fail(BFHIP_EHIP, "ifft_out launch: %s", hipGetErrorString(err));
     { int rv = do_subdelay(e, 1, nullptr); if (rv != BFHIP_OK) return rv; }
@@ -1514,7 +1550,7 @@ void bfhip_engine_destroy(bfhip_engine *e) {
                     e->d_bad, e->d_Zp, e->d_entries, e->d_chunks, e->d_rawin, e->d_rawout, e->d_taps,
                     e->d_fring, e->d_Y, e->d_Yold, e->d_evalprev, e->d_jobs,
                     e->d_dither_ch, e->d_dither_state, e->d_dither_table, e->d_randmap, e->d_skip_quant, e->d_timeout,
-                    e->d_big[0], e->d_big[1], e->d_big[2], e->d_tw13};
+                    e->d_big[0], e->d_big[1], e->d_big[2], e->d_tw13, e->d_tw_lo};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto ev : e->ev) (void)hipEventDestroy(ev);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -1837,10 +1873,25 @@ int bfhip_engine_finalize(bfhip_engine *e) {
             bytes += (double)cblocks_of(e, f.coeff, d) * e->L * e->csize() * std::max<size_t>(1, f.out_ch.size());
         }
         e->pipelined = bytes / 6.4e12 < 100e-6;
-        if (e->overlap_mode >= 0) e->pipelined = e->overlap_mode != 0;
-        if (const char *env = getenv("BFHIP_OVERLAP")) e->pipelined = atoi(env) != 0;
+        // (BFHIP_OVERLAP=2: pipeline a long MAC at L = 8192 too, with K1/K3 in 256-thread workgroups
+        // that fit on a CU next to a MAC workgroup -- 224 + 288 VGPRs per lane -- so that the side
+        // streams displace nothing.  Measured on config C: the transforms disappear behind the MAC
+        // but the MAC itself slows by 0.5-1.7 %; 1.364 -> 1.344 ms on one box, 1.414 -> 1.419 on
+        // another.  Not the default.  With the 1024-thread kernels on the side streams the MAC's
+        // workgroups used to be pushed together on fewer CUs: 1.74 ms.)
+        if (e->overlap_mode >= 0) { e->pipelined = e->overlap_mode != 0; e->lowfoot = e->lowfoot && e->pipelined; }
+        if (const char *env = getenv("BFHIP_OVERLAP")) {       // 0 off, 1 on (full-size kernels), 2 on (narrow kernels)
+            e->pipelined = atoi(env) != 0;
+            e->lowfoot = atoi(env) == 2 && e->log2L == 13 && e->rs == 4;
+        }
         for (int io = 0; io < 2; io++) for (int c : e->n_vpp[io]) if (c > 1) e->pipelined = false;   // one job table per side
         if (e->big) e->pipelined = false;          // one FFT scratch
+        if (!e->pipelined) e->lowfoot = false;
+    }
+    if (e->lowfoot) {
+        const std::vector<unsigned char> twlo = make_twiddle_table(13, e->rs, LO_NT);
+        HIPCHK(hipMalloc(&e->d_tw_lo, twlo.size()));
+        HIPCHK(hipMemcpy(e->d_tw_lo, twlo.data(), twlo.size(), hipMemcpyHostToDevice));
     }
     e->R = e->pipelined ? e->N + 1 : e->N;
     const size_t ring_b = (size_t)e->n_ch[0] * e->R * L * e->csize();

@@ -105,11 +105,12 @@ constexpr int tw_total(int log2l, int nt, int log2ns) {
 // 2L + q*NT + tid is register q of thread tid -- so that a wave fetches each register with one
 // contiguous 512-byte load instead of a 64-line gather (the gathers of 16 waves kept the CU's
 // texture path busy for ~3 us of a 17 us transform at L = 8192).
-// LAZY (float64 at L = 8192: 32 twiddles = 128 VGPRs, which made the kernels spill): nothing is
+// LAZY (more than 64 VGPRs of twiddles, e.g. float64 at L = 8192: 32 of them = 128 VGPRs, which
+// made the kernels spill; or a narrow workgroup with many butterflies per thread): nothing is
 // held in registers, every pass reads its twiddles from the thread-ordered table when it needs
 // them -- still one coalesced load per value.
 template <typename T, int LOG2L, int NT> struct TwRegs {
-    static constexpr bool LAZY = sizeof(T) == 8 && LOG2L >= 13;
+    static constexpr bool LAZY = (size_t)tw_total(LOG2L, NT, 0) * sizeof(c2<T>) > 256;     // > 64 VGPRs
     static constexpr int N = (LAZY || tw_total(LOG2L, NT, 0) == 0) ? 1 : tw_total(LOG2L, NT, 0);
     c2<T> r[N];
     const c2<T> *g;                 // thread-ordered table, this thread's column

@@ -172,8 +172,8 @@ __device__ __forceinline__ void store_raw_bytes(uint8_t *p, const uint8_t *t, in
 // helpers shared by the kernels that run the in-LDS real FFTs --------------------------
 
 // bins this thread untangles: k = 1 + tid + i*NT (i < QU) covers 1..L/2; k = 0 is thread 0's
-template <typename T, int LOG2L> struct UT {
-    static constexpr int L = 1 << LOG2L, NT = fft_threads<T>(LOG2L);
+template <typename T, int LOG2L, int NTP = fft_threads<T>(LOG2L)> struct UT {
+    static constexpr int L = 1 << LOG2L, NT = NTP;
     static constexpr int QU = (L / 2 + NT - 1) / NT;     // bins (pairs k, L-k) per thread
     static constexpr int QP = (L / 2 + NT - 1) / NT;     // sample pairs per thread and half
 };
@@ -201,14 +201,14 @@ __device__ __forceinline__ void tangle(c2<T> a, c2<T> bconj, c2<T> w, c2<T> &zk,
 // (fftw_convolver.c:181-193); z[n] = x[2n] + i x[2n+1]; complex FFT; untangle; write the
 // packed spectrum into ring slot `slot` of that channel.  All global loads (twiddles,
 // previous block, raw samples) are issued before anything waits on them.
-template <typename T, int LOG2L>
+template <typename T, int LOG2L, int NTP = fft_threads<T>(LOG2L)>
 __device__ __forceinline__ void
 fft_in_body(int ch, unsigned char *smem, const uint8_t *__restrict__ raw, const DevFormat *__restrict__ fmt,
             T *__restrict__ prev,            // [n_in][L] last block's samples
             c2<T> *__restrict__ ring,        // [n_in][R][L]
             const c2<T> *__restrict__ tw, int R, int slot) {
-    constexpr int L = 1 << LOG2L, NT = fft_threads<T>(LOG2L);
-    constexpr int QP = UT<T, LOG2L>::QP, QU = UT<T, LOG2L>::QU;
+    constexpr int L = 1 << LOG2L, NT = NTP;
+    constexpr int QP = UT<T, LOG2L, NT>::QP, QU = UT<T, LOG2L, NT>::QU;
     LdsArr<T> s{reinterpret_cast<c2<T> *>(smem)};
     const int tid = threadIdx.x;
     const DevFormat f = fmt[ch];
@@ -277,14 +277,14 @@ fft_in_body(int ch, unsigned char *smem, const uint8_t *__restrict__ raw, const 
     BF_PROBE(11);
 }
 
-template <typename T, int LOG2L>
-__global__ __launch_bounds__(fft_threads<T>(LOG2L)) void
+template <typename T, int LOG2L, int NTP = fft_threads<T>(LOG2L)>
+__global__ __launch_bounds__(NTP) void
 fft_in_kernel(const uint8_t *__restrict__ raw, const DevFormat *__restrict__ fmt, T *__restrict__ prev,
               c2<T> *__restrict__ ring, const c2<T> *__restrict__ tw, int R, int slot,
               const BlockState *__restrict__ bs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (bs) slot = (int)(bs->t % (unsigned int)R);
-    fft_in_body<T, LOG2L>(blockIdx.x, smem, raw, fmt, prev, ring, tw, R, slot);
+    fft_in_body<T, LOG2L, NTP>(blockIdx.x, smem, raw, fmt, prev, ring, tw, R, slot);
 }
 
 // ------------------------------------------------------------------ K7: taps -> coefficient partition
@@ -968,7 +968,7 @@ real2int_no_dither(double v, double rmin, double rmax, int32_t imin, int32_t ima
 // float store, peak + overflow accounting, strided interleaved write.
 // `timeout` (may be NULL): if given, the samples are ALSO stored there as T [count][L]
 // (used by the dither pass and by debug taps).
-template <typename T, int LOG2L>
+template <typename T, int LOG2L, int NTP = fft_threads<T>(LOG2L)>
 __device__ __forceinline__ void
 ifft_out_body(int zi /* index into Zp's channel axis */, unsigned char *smem,
               const c2<T> *__restrict__ Zp, size_t chunk_stride, int n_chunks,
@@ -976,8 +976,8 @@ ifft_out_body(int zi /* index into Zp's channel axis */, unsigned char *smem,
               DevOverflow *__restrict__ over, const unsigned char *__restrict__ skip_quant,
               uint8_t *__restrict__ raw, T *__restrict__ timeout,
               const c2<T> *__restrict__ tw, double safety_limit, int *__restrict__ status) {
-    constexpr int L = 1 << LOG2L, NT = fft_threads<T>(LOG2L);
-    constexpr int QU = UT<T, LOG2L>::QU;
+    constexpr int L = 1 << LOG2L, NT = NTP;
+    constexpr int QU = UT<T, LOG2L, NT>::QU;
     LdsArr<T> s{reinterpret_cast<c2<T> *>(smem)};
     __shared__ unsigned int red_n[16];
     __shared__ int32_t red_i[16];
@@ -1130,15 +1130,15 @@ ifft_out_body(int zi /* index into Zp's channel axis */, unsigned char *smem,
     }
 }
 
-template <typename T, int LOG2L>
-__global__ __launch_bounds__(fft_threads<T>(LOG2L)) void
+template <typename T, int LOG2L, int NTP = fft_threads<T>(LOG2L)>
+__global__ __launch_bounds__(NTP) void
 ifft_out_kernel(const c2<T> *__restrict__ Zp, size_t chunk_stride, int n_chunks, int first_channel,
                 const DevFormat *__restrict__ fmt, DevOverflow *__restrict__ over,
                 const unsigned char *__restrict__ skip_quant, uint8_t *__restrict__ raw,
                 T *__restrict__ timeout, const c2<T> *__restrict__ tw, double safety_limit,
                 int *__restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    ifft_out_body<T, LOG2L>(blockIdx.x, smem, Zp, chunk_stride, n_chunks, first_channel, fmt, over,
+    ifft_out_body<T, LOG2L, NTP>(blockIdx.x, smem, Zp, chunk_stride, n_chunks, first_channel, fmt, over,
                             skip_quant, raw, timeout, tw, safety_limit, status);
 }
 
