@@ -16,7 +16,8 @@ def _as_samples(raw, fmt):
     return np.frombuffer(raw.tobytes(), cases.RAW_NP[fmt]).astype(np.float64)
 
 
-@pytest.mark.parametrize("L,N,I,O", [(64, 4, 2, 2), (256, 8, 3, 5), (8192, 8, 8, 8)])
+@pytest.mark.parametrize("L,N,I,O", [(64, 4, 2, 2), (256, 8, 3, 5), (8192, 8, 8, 8),
+                                     (256, 37, 1, 8), (128, 5, 3, 16), (512, 2, 9, 24)])   # all-crossbar plans: the pipelined MAC
 def test_crossbar_matches_oracle_f32(hip, L, N, I, O):
     """S24_4LE in, FLOAT_LE out: the float32 tolerance of north_star on unquantised samples"""
     ifmt, ofmt = "S24_4LE", "FLOAT_LE"
