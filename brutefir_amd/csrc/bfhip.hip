@@ -553,30 +553,11 @@ int big_reserve(bfhip_engine *e, size_t n_tr) {
 // zin -> zout: complex FFT of L points for n_tr transforms on `st`
 template <typename T>
 void big_fft(bfhip_engine *e, int n_tr, bool inv, hipStream_t st, hipError_t *err) {
-    constexpr int NT = fft_threads<T>(BIG_LOG2M);
-    const size_t lds = lds_fft_bytes(BIG_LOG2M, sizeof(c2<T>));
     const c2<T> *zin = (const c2<T> *)e->d_big[0];
     c2<T> *zmid = (c2<T> *)e->d_big[1], *zout = (c2<T> *)e->d_big[2];
     const c2<T> *tw13 = (const c2<T> *)e->d_tw13, *twL = (const c2<T> *)e->d_tw;
-    const int R = e->big_R;
-    if (inv) {
-        auto ka = big_fft_a<T, true>;
-        if ((*err = allow_lds(ka, lds)) != hipSuccess) return;
-        hipLaunchKernelGGL(ka, dim3(R, n_tr), dim3(NT), lds, st, zin, zmid, R, tw13);
-        const dim3 gb(BIG_M / 256, n_tr);
-        if (R == 2) hipLaunchKernelGGL((big_fft_b<T, true, 2>), gb, dim3(256), 0, st, (const c2<T> *)zmid, zout, twL);
-        else if (R == 4) hipLaunchKernelGGL((big_fft_b<T, true, 4>), gb, dim3(256), 0, st, (const c2<T> *)zmid, zout, twL);
-        else hipLaunchKernelGGL((big_fft_b<T, true, 8>), gb, dim3(256), 0, st, (const c2<T> *)zmid, zout, twL);
-    } else {
-        auto ka = big_fft_a<T, false>;
-        if ((*err = allow_lds(ka, lds)) != hipSuccess) return;
-        hipLaunchKernelGGL(ka, dim3(R, n_tr), dim3(NT), lds, st, zin, zmid, R, tw13);
-        const dim3 gb(BIG_M / 256, n_tr);
-        if (R == 2) hipLaunchKernelGGL((big_fft_b<T, false, 2>), gb, dim3(256), 0, st, (const c2<T> *)zmid, zout, twL);
-        else if (R == 4) hipLaunchKernelGGL((big_fft_b<T, false, 4>), gb, dim3(256), 0, st, (const c2<T> *)zmid, zout, twL);
-        else hipLaunchKernelGGL((big_fft_b<T, false, 8>), gb, dim3(256), 0, st, (const c2<T> *)zmid, zout, twL);
-    }
-    *err = hipGetLastError();
+    *err = inv ? big_fft_run<T, true>(zin, zmid, zout, e->log2L, n_tr, tw13, twL, st)
+               : big_fft_run<T, false>(zin, zmid, zout, e->log2L, n_tr, tw13, twL, st);
 }
 
 inline dim3 big_grid_half(const bfhip_engine *e, int n_tr) { return dim3((unsigned)(e->L / 2 / 256 + 1), (unsigned)n_tr); }
@@ -1463,8 +1444,8 @@ bfhip_engine *bfhip_engine_create(int device, int length, int n_blocks, int real
                                   int n_in, int n_out) {
     if (realsize != 4 && realsize != 8) { fail(BFHIP_EINVAL, "Invalid real size %d.", realsize); return nullptr; }
     const int lg = ilog2(length);
-    if (lg < 2 || lg > 16) {
-        fail(BFHIP_EINVAL, "Invalid length %d (power of two in 4..65536 required).", length);
+    if (lg < 2 || lg > 20) {
+        fail(BFHIP_EINVAL, "Invalid length %d (power of two in 4..1048576 required).", length);
         return nullptr;
     }
     if (n_blocks < 1 || n_in < 1 || n_out < 1) { fail(BFHIP_EINVAL, "bad n_blocks/n_in/n_out"); return nullptr; }
@@ -1894,6 +1875,9 @@ int bfhip_engine_finalize(bfhip_engine *e) {
         HIPCHK(hipMemcpy(e->d_tw_lo, twlo.data(), twlo.size(), hipMemcpyHostToDevice));
     }
     e->R = e->pipelined ? e->N + 1 : e->N;
+    // the MAC addresses a ring / a coefficient set with 32-bit byte offsets from its base
+    if ((double)(e->N + 1) * (double)L * (double)e->csize() >= 4294967296.0)
+        return fail(BFHIP_EINVAL, "%d partitions of %d taps: a coefficient set would exceed 4 GiB", e->N, e->L);
     const size_t ring_b = (size_t)e->n_ch[0] * e->R * L * e->csize();
     if (hipMalloc(&e->d_prev, prev_b) != hipSuccess || hipMalloc(&e->d_ring, ring_b) != hipSuccess)
         return fail(BFHIP_ENOMEM, "out of device memory for the spectrum rings");

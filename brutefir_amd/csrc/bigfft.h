@@ -1,4 +1,4 @@
-// bigfft.h -- partition lengths above the LDS limit (L = 16384 ... 65536).
+// bigfft.h -- partition lengths above the LDS limit (L = 16384 ... 1048576).
 //
 // BruteFIR's stock configuration is ONE partition of 65536 taps (`filter_length: 65536;`,
 // bfconf.c:197, bench3_config) and any power of two is legal (bfconf.c:1512-1514).  A complex
@@ -7,11 +7,14 @@
 //
 //     pre   (elementwise: window / tangle / mix ...  -> zin[transform][L])
 //     A     R = L/8192 LDS transforms of M = 8192 points per transform, on the decimated
-//           subsequences z[r + R m]                        -> zmid[transform][r][k]
-//     B     radix-R combine with twiddles W_L^(r k)         -> zout[transform][k + M q]
+//           subsequences z[r + R m]                        -> [transform][r][k]
+//     B     combine passes of radix <= 8 (one for R <= 8, up to three for R = 128), each
+//           merging Rp sub-transforms of length Mc into one of length Mc Rp with twiddles
+//           W_(Mc Rp)^(j k)                                 -> zout[transform][L]
 //     post  (elementwise: untangle / quantise / ramp ...)
 //
-// (decimation in time: X[k + M q] = sum_r W_R^(r q) (W_L^(r k) Y_r[k]), Y_r = FFT_M of z[r + R m]).
+// (decimation in time: X[k + Mc q] = sum_j W_Rp^(j q) (W_(Mc Rp)^(j k) Y_j[k]); with r = r1 + R1 r2
+// the first pass merges over the high digit r2, the next over r1, ...).
 // The block period at these lengths is a third of a second and more; the extra launches and
 // the global round trips do not matter, the MAC (kernels.h, any L) still dominates.
 // Arithmetic and bookkeeping are the same statements as in the LDS kernels, so every feature
@@ -41,26 +44,64 @@ big_fft_a(const c2<T> *__restrict__ zin, c2<T> *__restrict__ zmid, int R, const 
     for (int k = tid; k < M; k += NT) zmid[base + (size_t)r * M + k] = s[k];
 }
 
-// ---- stage B: one thread per k in [0, M): twiddle, DFT_R across the R partial transforms
-template <typename T, bool INV, int R>
+// ---- stage B, one combine pass: S = Gp * RP sub-transforms of length Mc (sub s at s * Mc) become Gp
+// of length Mc * RP; sub-transform g of the result merges the inputs s = g + Gp * j, j < RP.
+// One thread per (g, k).  tw_stride = L / (Mc * RP): W_(Mc RP)^(j k) = twL[2 j k tw_stride].
+template <typename T, bool INV, int RP>
 __global__ __launch_bounds__(256) void
-big_fft_b(const c2<T> *__restrict__ zmid, c2<T> *__restrict__ zout, const c2<T> *__restrict__ twL) {
-    constexpr int M = BIG_M;
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    const size_t base = (size_t)blockIdx.y * M * R;
-    c2<T> u[R];
+big_fft_b(const c2<T> *__restrict__ zin, c2<T> *__restrict__ zout, const c2<T> *__restrict__ twL,
+          int Mc, int Gp, int tw_stride, size_t L) {
+    const int i = blockIdx.x * 256 + threadIdx.x;          // < Gp * Mc
+    const int g = i / Mc, k = i - g * Mc;
+    const size_t base = (size_t)blockIdx.y * L;
+    c2<T> u[RP];
 #pragma unroll
-    for (int r = 0; r < R; r++) {
-        u[r] = zmid[base + (size_t)r * M + k];
-        if (r > 0) {
-            c2<T> w = twL[2 * (r * k)];                 // exp(-2 pi i r k / L)
+    for (int j = 0; j < RP; j++) {
+        u[j] = zin[base + (size_t)(g + Gp * j) * Mc + k];
+        if (j > 0) {
+            c2<T> w = twL[(size_t)2 * j * k * tw_stride];
             if (INV) w.y = -w.y;
-            u[r] = cmul(u[r], w);
+            u[j] = cmul(u[j], w);
         }
     }
-    dftR<T, INV, R>(u);
+    dftR<T, INV, RP>(u);
 #pragma unroll
-    for (int q = 0; q < R; q++) zout[base + (size_t)k + (size_t)M * q] = u[q];
+    for (int q = 0; q < RP; q++) zout[base + (size_t)g * Mc * RP + k + (size_t)Mc * q] = u[q];
+}
+
+// ---- host: the complete complex FFT of 2^log2L points for n_tr transforms, zin -> zout.
+// zmid and zout are used alternately by the combine passes so that the last one lands in zout.
+template <typename T, bool INV, int RP>
+inline void big_fft_launch_b(const c2<T> *in, c2<T> *out, const c2<T> *twL, int Mc, int Gp, int tw_stride,
+                             size_t L, int n_tr, hipStream_t st) {
+    hipLaunchKernelGGL((big_fft_b<T, INV, RP>), dim3((unsigned)((size_t)Mc * Gp / 256), (unsigned)n_tr), dim3(256), 0, st,
+                       in, out, twL, Mc, Gp, tw_stride, L);
+}
+
+template <typename T, bool INV>
+inline hipError_t big_fft_run(const c2<T> *zin, c2<T> *zmid, c2<T> *zout, int log2L, int n_tr,
+                              const c2<T> *tw13, const c2<T> *twL, hipStream_t st) {
+    constexpr int NT = fft_threads<T>(BIG_LOG2M);
+    const size_t lds = lds_fft_bytes(BIG_LOG2M, sizeof(c2<T>));
+    const size_t L = (size_t)1 << log2L;
+    const int R = (int)(L / BIG_M);
+    int bits = log2L - BIG_LOG2M, passes = (bits + 2) / 3;
+    auto ka = big_fft_a<T, INV>;
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (err != hipSuccess) return err;
+    c2<T> *buf[2] = {zout, zmid};
+    int cur = passes & 1;                              // after `passes` flips the data is in buf[0] = zout
+    hipLaunchKernelGGL(ka, dim3(R, n_tr), dim3(NT), lds, st, zin, buf[cur], R, tw13);
+    int Mc = BIG_M, S = R;
+    while (bits > 0) {
+        const int b = bits >= 3 ? 3 : bits, RP = 1 << b, Gp = S / RP;
+        const int tw_stride = (int)(L / ((size_t)Mc * RP));
+        if (RP == 8) big_fft_launch_b<T, INV, 8>(buf[cur], buf[cur ^ 1], twL, Mc, Gp, tw_stride, L, n_tr, st);
+        else if (RP == 4) big_fft_launch_b<T, INV, 4>(buf[cur], buf[cur ^ 1], twL, Mc, Gp, tw_stride, L, n_tr, st);
+        else big_fft_launch_b<T, INV, 2>(buf[cur], buf[cur ^ 1], twL, Mc, Gp, tw_stride, L, n_tr, st);
+        cur ^= 1; Mc *= RP; S = Gp; bits -= b;
+    }
+    return hipGetLastError();
 }
 
 // ---- K1 ------------------------------------------------------------------------------------

@@ -458,7 +458,7 @@ void fft_launch(bool inverse, const void *in, void *out) {
 // through the scratch buffers)
 template <typename T>
 bool big_fft_launch(int log2c, bool inverse, const void *in, void *out) {
-    const int L = 1 << log2c, R = L / BIG_M;
+    const int L = 1 << log2c;
     const size_t bytes = (size_t)L * sizeof(c2<T>);
     for (int i = 0; i < 3; i++) {
         if (G.big_bytes[i] < bytes) {
@@ -471,34 +471,24 @@ bool big_fft_launch(int log2c, bool inverse, const void *in, void *out) {
     c2<T> *zin = (c2<T> *)G.d_big[0], *zmid = (c2<T> *)G.d_big[1], *zout = (c2<T> *)G.d_big[2];
     const c2<T> *twL = (const c2<T> *)twiddles(log2c), *tw13 = (const c2<T> *)twiddles(BIG_LOG2M);
     if (!twL || !tw13) return false;
-    constexpr int NT = fft_threads<T>(BIG_LOG2M);
-    const size_t lds = lds_fft_bytes(BIG_LOG2M, sizeof(c2<T>));
-    const dim3 gh((unsigned)(L / 2 / 256 + 1)), gf((unsigned)(L / 256)), gb(BIG_M / 256, 1);
-    if (inverse) hipLaunchKernelGGL(k_big_hc2r_pre<T>, gh, dim3(256), 0, G.stream, (const T *)in, zin, twL, L);
-    else hipLaunchKernelGGL(k_big_pack<T>, gf, dim3(256), 0, G.stream, (const T *)in, zin, L);
+    const dim3 gh((unsigned)(L / 2 / 256 + 1)), gf((unsigned)(L / 256));
+    hipError_t ferr;
     if (inverse) {
-        auto ka = big_fft_a<T, true>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(ka, dim3(R, 1), dim3(NT), lds, G.stream, (const c2<T> *)zin, zmid, R, tw13);
-        if (R == 2) hipLaunchKernelGGL((big_fft_b<T, true, 2>), gb, dim3(256), 0, G.stream, (const c2<T> *)zmid, zout, twL);
-        else if (R == 4) hipLaunchKernelGGL((big_fft_b<T, true, 4>), gb, dim3(256), 0, G.stream, (const c2<T> *)zmid, zout, twL);
-        else hipLaunchKernelGGL((big_fft_b<T, true, 8>), gb, dim3(256), 0, G.stream, (const c2<T> *)zmid, zout, twL);
+        hipLaunchKernelGGL(k_big_hc2r_pre<T>, gh, dim3(256), 0, G.stream, (const T *)in, zin, twL, L);
+        ferr = big_fft_run<T, true>((const c2<T> *)zin, zmid, zout, log2c, 1, tw13, twL, G.stream);
         hipLaunchKernelGGL(k_big_unpack<T>, gf, dim3(256), 0, G.stream, (const c2<T> *)zout, (T *)out, L);
     } else {
-        auto ka = big_fft_a<T, false>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(ka, dim3(R, 1), dim3(NT), lds, G.stream, (const c2<T> *)zin, zmid, R, tw13);
-        if (R == 2) hipLaunchKernelGGL((big_fft_b<T, false, 2>), gb, dim3(256), 0, G.stream, (const c2<T> *)zmid, zout, twL);
-        else if (R == 4) hipLaunchKernelGGL((big_fft_b<T, false, 4>), gb, dim3(256), 0, G.stream, (const c2<T> *)zmid, zout, twL);
-        else hipLaunchKernelGGL((big_fft_b<T, false, 8>), gb, dim3(256), 0, G.stream, (const c2<T> *)zmid, zout, twL);
+        hipLaunchKernelGGL(k_big_pack<T>, gf, dim3(256), 0, G.stream, (const T *)in, zin, L);
+        ferr = big_fft_run<T, false>((const c2<T> *)zin, zmid, zout, log2c, 1, tw13, twL, G.stream);
         hipLaunchKernelGGL(k_big_r2hc_post<T>, gh, dim3(256), 0, G.stream, (const c2<T> *)zout, (T *)out, twL, L);
     }
+    if (ferr != hipSuccess) return false;
     return hipGetLastError() == hipSuccess;
 }
 
 // device-side real FFT of 2^(log2c+1) reals, buffers on the device
 bool dev_fft(int log2c, bool inverse, const void *in, void *out) {
-    if (log2c > BIG_LOG2M && log2c <= 16)
+    if (log2c > BIG_LOG2M && log2c <= 20)
         return G.rs == 4 ? big_fft_launch<float>(log2c, inverse, in, out) : big_fft_launch<double>(log2c, inverse, in, out);
 #define CASE(n) case n: if (G.rs == 4) fft_launch<float, n>(inverse, in, out); else fft_launch<double, n>(inverse, in, out); break;
     switch (log2c) {
@@ -579,7 +569,7 @@ int convolver_init(const char config_filename[], int length, int realsize) {
     int order = 0;
     while ((1 << order) < length) order++;
     if (length < 1 || (1 << order) != length) { fprintf(stderr, "Invalid length %d.\n", length); return 0; }
-    if (order > 16) { fprintf(stderr, "Invalid length %d (the device path supports up to 65536).\n", length); return 0; }
+    if (order > 20) { fprintf(stderr, "Invalid length %d (the device path supports up to 1048576).\n", length); return 0; }
     G.L = length; G.rs = realsize; G.log2L = order; G.inited = true; G.last_fatal = 0;
     G.pid = 0;                                 /* device comes up lazily, per process */
     return 1;

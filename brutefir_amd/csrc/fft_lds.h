@@ -210,7 +210,8 @@ __device__ __forceinline__ void lds_fft(LdsArr<T> s, const TwRegs<T, LOG2L, NT> 
 // kernels of this precision use.  Values are computed in double and rounded once.
 inline std::vector<unsigned char> make_twiddle_table(int log2l, int realsize, int nt) {
     const size_t L = (size_t)1 << log2l;
-    const size_t n_regs = (size_t)tw_total(log2l, nt, 0);
+    // lengths above the LDS limit (bigfft.h) only use the base table
+    const size_t n_regs = log2l > 13 ? 0 : (size_t)tw_total(log2l, nt, 0);
     const size_t total = 2 * L + n_regs * (size_t)nt;
     std::vector<unsigned char> out(total * 2 * (size_t)realsize);
     auto put = [&](size_t idx, size_t m) {
@@ -220,7 +221,7 @@ inline std::vector<unsigned char> make_twiddle_table(int log2l, int realsize, in
     };
     for (size_t m = 0; m < 2 * L; m++) put(m, m);
     size_t q = 0;
-    for (int log2ns = 0; log2ns < log2l; log2ns += pass_log2r(log2l, log2ns)) {
+    for (int log2ns = 0; n_regs > 0 && log2ns < log2l; log2ns += pass_log2r(log2l, log2ns)) {
         const int log2r = pass_log2r(log2l, log2ns);
         const int R = 1 << log2r, Ns = 1 << log2ns, TT = (int)L / R;
         const int B = pass_b(log2l, nt, log2ns), NTW = pass_ntw(log2l, log2ns);

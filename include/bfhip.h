@@ -81,7 +81,7 @@ const char *bfhip_version(void);
 
 /* convolver_init(wisdom, length, realsize) (fftw_convolver.c:784-851) + the buffer set-up of
    filter_process() (bfrun.c:1227-1304, all zeroed as at :1388).  length = partition size L
-   (power of two, 4..65536: up to 8192 the transforms run in LDS, above as multi-kernel
+   (power of two, 4..1048576: up to 8192 the transforms run in LDS, above as multi-kernel
    sequences over global memory; the reference's stock `filter_length: 65536` is covered), n_blocks = N partitions per filter, realsize 4 or 8.
    n_raw_in/out: size in bytes of one raw input / output buffer (dai_buffer_format->n_bytes).
    Device initialisation happens here, lazily on first use of the process: call it in the

@@ -12,7 +12,8 @@ from test_gpu_features import _compare, _ir, _spec, FLOATFMT, TOL
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("L,N,rs", [(16384, 2, 4), (32768, 1, 4), (65536, 1, 4), (65536, 2, 8), (16384, 3, 8)])
+@pytest.mark.parametrize("L,N,rs", [(16384, 2, 4), (32768, 1, 4), (65536, 1, 4), (65536, 2, 8), (16384, 3, 8),
+                                    (131072, 1, 4), (262144, 2, 8), (524288, 1, 4), (1048576, 1, 8)])
 def test_crossbar_long_partitions(hip, L, N, rs):
     """bench3_config's shape: few channels, one or two very long partitions"""
     I, O = 2, 2
@@ -106,7 +107,7 @@ def test_tiny_partitions(hip, L, rs):
 
 def test_length_limits(hip):
     with pytest.raises(hip.BfhipError, match="Invalid length"):
-        hip.Engine(131072, 1, 4, 1, 1)
+        hip.Engine(2097152, 1, 4, 1, 1)
     with pytest.raises(hip.BfhipError, match="Invalid length"):
         hip.Engine(2, 4, 4, 1, 1)
     with pytest.raises(hip.BfhipError, match="Invalid length"):

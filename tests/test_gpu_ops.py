@@ -123,7 +123,7 @@ def test_sample_conversion_bit_exact_vs_reference(cv, rs, tag, _):
 
 
 @pytest.mark.parametrize("rs,tag,tol", PREC)
-@pytest.mark.parametrize("L", [64, 1024, 8192, 16384, 65536])
+@pytest.mark.parametrize("L", [64, 1024, 8192, 16384, 65536, 262144])
 def test_fft_ops_vs_definition(cv, rs, tag, tol, L):
     dt = np.float32 if rs == 4 else np.float64
     assert cv.convolver_init(None, L, rs) == 1
