@@ -11,6 +11,11 @@
  * Segment k must start at a tap >= seg_length[k] - seg_length[0] so that its result is ready
  * when needed (checked); "2 x 64, 2 x 128, 2 x 256, ..." style schedules satisfy it.
  *
+ * Scheduling: a segment whose first output frame is due later than the period it is launched in
+ * (every segment but the first in the doubling schedule) runs on its own low-priority stream
+ * beside the periods that follow; the main stream waits for it only when its output is due, so
+ * the longest period costs about what the common one does (tools/nupc_latency.py).
+ *
  * Filters are single-input single-output impulse responses (a crossbar is one call per pair).
  * Raw I/O buffers hold interleaved frames (dai.c's interleaved layout): all channels of a side
  * share sample_spacing and bytes.
@@ -42,6 +47,8 @@ int bfhip_nupc_finalize(bfhip_nupc *n);
 int bfhip_nupc_block(bfhip_nupc *n, const void *rawin, void *rawout, bfhip_overflow overflow[]);
 /* device-resident buffers, asynchronous on the convolver's stream */
 int bfhip_nupc_block_dev(bfhip_nupc *n, const void *rawin_dev, void *rawout_dev);
+/* waits for the periods handed in so far and returns the status bits collected since the last
+   call (background segment blocks that are not due yet keep running) */
 int bfhip_nupc_sync(bfhip_nupc *n);
 int bfhip_nupc_get_overflow(bfhip_nupc *n, int out_channel, bfhip_overflow *of);
 
