@@ -1359,6 +1359,24 @@ subdelay_fir_kernel(const SdJob<T> *__restrict__ jobs, int L, int bs, int flen) 
 // first sample), so the device keeps the table immutable and carries the byte in a register.
 template <typename T> struct DitherState { int ptr; int pad; T s0, s1; };
 
+// wave-uniform value of lane `i` (i is uniform): v_readlane, no LDS round trip
+__device__ __forceinline__ float lane_value(float v, int i) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i));
+}
+__device__ __forceinline__ double lane_value(double v, int i) {
+    const long long b = __double_as_longlong(v);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(b & 0xffffffffll), i);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(b >> 32), i);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// The quantiser is an error-feedback loop (dither_funs.h:7-68: sample n needs the errors of n-1
+// and n-2), so a channel is a serial chain; everything that is NOT part of the chain is done 64
+// samples at a time by the wave: loading the samples, looking up the dither values
+// randmap[r[n] - r[n-1]] (their indices depend on n only), the finite / safety tests, and the
+// byte stores.  The chain itself runs on wave-uniform values fetched with v_readlane -- no
+// memory access inside it -- and lane i keeps sample i's integer.  (The first version walked
+// the samples with one lane and a table load per sample: 6 ms per 8192-sample block.)
 template <typename T>
 __global__ __launch_bounds__(64) void
 dither_kernel(const T *__restrict__ samples,          // [n_out][L] from ifft_out_kernel
@@ -1367,9 +1385,7 @@ dither_kernel(const T *__restrict__ samples,          // [n_out][L] from ifft_ou
               const T *__restrict__ randmap,          // index -256..255 (centre pointer)
               const DevFormat *__restrict__ fmt, DevOverflow *__restrict__ over,
               uint8_t *__restrict__ raw, int L, double safety_limit, int *__restrict__ status) {
-    constexpr int CH = 512;
-    __shared__ T xs[CH];
-    __shared__ int8_t rs[CH + 1];
+    __shared__ T rmap[512];
     const int slot = blockIdx.x, lane = threadIdx.x;
     const int ch = channels[slot];
     const DevFormat f = fmt[ch];
@@ -1380,63 +1396,88 @@ dither_kernel(const T *__restrict__ samples,          // [n_out][L] from ifft_ou
     const int32_t imin = (int32_t)(-((uint64_t)1 << (bits - 1)));
     const int32_t imax = (int32_t)(((uint64_t)1 << (bits - 1)) - 1);
     const T rmin = (T)imin, rmax = (T)imax;
+    for (int i = lane; i < 512; i += 64) rmap[i] = randmap[i - 256];
+    __syncthreads();
 
-    DitherState<T> st = state[slot];
+    const DitherState<T> st = state[slot];
     DevOverflow of = over[ch];
     int ptr = st.ptr;
     const int8_t pred = table[ptr - 1];
     if (ptr + L >= table_size) ptr = 1;                 // dither_preloop_real2int_hp_tpdf
     const int8_t *tab = table + ptr;
-    int8_t prev_r = pred;
+    T s0 = st.s0, s1 = st.s1;
+    unsigned int n_over = of.n_overflows;
+    int32_t intlargest = of.intlargest;
+    double largest = of.largest;
+    const double lim = safety_limit * of.max;
     int flags = 0;
 
-    for (int c0 = 0; c0 < L; c0 += CH) {
-        const int cn = min(CH, L - c0);
-        __syncthreads();
-        for (int i = lane; i < cn; i += 64) { xs[i] = x[c0 + i]; rs[i] = tab[c0 + i]; }
-        __syncthreads();
-        if (lane == 0) {
-            for (int i = 0; i < cn; i++) {
-                T v = xs[i];
-                const int8_t r = rs[i];
-                uint8_t *p = base + (size_t)(c0 + i) * stride;
-                if (!isfinite(v)) { flags |= 1; prev_r = r; continue; }
-                if (safety_limit != 0.0 && ((double)v < -safety_limit * of.max || (double)v > safety_limit * of.max)) {
-                    flags |= 2; prev_r = r; continue;
-                }
-                v += st.s0 - st.s1;
-                st.s1 = st.s0;
-                const T dv = v + randmap[(int)r - (int)prev_r];
-                prev_r = r;
-                int32_t q;
-                if (dv < 0) {
-                    if (dv <= rmin) {
-                        q = imin; of.n_overflows++;
-                        if ((double)v < -of.largest) of.largest = (double)-dv;
-                    } else {
-                        q = (int32_t)dv; q--;
-                        if (q < -of.intlargest) of.intlargest = -q;
-                    }
-                } else {
-                    if (dv > rmax) {
-                        q = imax; of.n_overflows++;
-                        if ((double)v > of.largest) of.largest = (double)dv;
-                    } else {
-                        q = (int32_t)dv;
-                        if (q > of.intlargest) of.intlargest = q;
-                    }
-                }
-                st.s0 = v - (T)q;
-                const uint32_t u = (uint32_t)q;
-                uint8_t tb[4] = {(uint8_t)(u & 0xff), (uint8_t)((u >> 8) & 0xff), (uint8_t)((u >> 16) & 0xff), (uint8_t)(u >> 24)};
-                store_raw_bytes(p, tb, f.bytes, f.swap);
+    for (int c0 = 0; c0 < L; c0 += 64) {
+        const int n = c0 + lane;
+        const bool valid = n < L;
+        const T xv = valid ? x[n] : (T)0;
+        const int r = valid ? (int)tab[n] : 0;
+        const int rp = n == 0 ? (int)pred : (valid ? (int)tab[n - 1] : 0);
+        const T dth = rmap[256 + r - rp];
+        int skip = valid ? 0 : 1;
+        if (valid && !isfinite(xv)) { flags |= 1; skip = 1; }
+        else if (valid && safety_limit != 0.0 && ((double)xv < -lim || (double)xv > lim)) { flags |= 2; skip = 1; }
+        int32_t myq = 0;
+        T myfb = (T)0;
+#pragma unroll 8
+        for (int i = 0; i < 64; i++) {
+            const T xi = lane_value(xv, i), di = lane_value(dth, i);
+            const bool sk = __builtin_amdgcn_readlane(skip, i) != 0;
+            // dither_funs.h:21-66 on uniform values; only what the next sample needs is in here
+            const T fb = s0 - s1;
+            const T v = xi + fb;
+            const T dv = v + di;
+            const bool neg = dv < (T)0;
+            const bool clip = neg ? (dv <= rmin) : (dv > rmax);
+            int32_t q = (int32_t)(clip ? (T)0 : dv);
+            q = neg ? q - 1 : q;
+            q = clip ? (neg ? imin : imax) : q;
+            const T e0 = v - (T)q;
+            s1 = sk ? s1 : s0;
+            s0 = sk ? s0 : e0;
+            if (lane == i) { myq = q; myfb = fb; }
+        }
+        // the bookkeeping of dither_funs.h:33-60 from each lane's own sample: the overflow count
+        // and the largest integer are order independent; `largest` (compares the undithered,
+        // stores the dithered value) is walked in sample order over the clipped samples only
+        {
+            const T v = xv + myfb;
+            const T dv = v + dth;
+            const bool neg = dv < (T)0;
+            const bool clip = !skip && (neg ? (dv <= rmin) : (dv > rmax));
+            int32_t mag = (skip || clip) ? 0 : (neg ? -myq : myq);
+            for (int off = 32; off > 0; off >>= 1) { const int32_t o = __shfl_xor(mag, off); mag = o > mag ? o : mag; }
+            if (mag > intlargest) intlargest = mag;
+            unsigned long long cm = __ballot(clip);
+            n_over += (unsigned int)__popcll(cm);
+            while (cm) {
+                const int i = __ffsll((long long)cm) - 1;
+                cm &= cm - 1;
+                const double vi = (double)lane_value(v, i), dvi = (double)lane_value(dv, i);
+                if (dvi < 0) { if (vi < -largest) largest = -dvi; }
+                else { if (vi > largest) largest = dvi; }
             }
         }
+        if (!skip) {
+            const uint32_t u = (uint32_t)myq;
+            uint8_t tb[4] = {(uint8_t)(u & 0xff), (uint8_t)((u >> 8) & 0xff), (uint8_t)((u >> 16) & 0xff), (uint8_t)(u >> 24)};
+            store_raw_bytes(base + (size_t)n * stride, tb, f.bytes, f.swap);
+        }
     }
+    for (int off = 32; off > 0; off >>= 1) flags |= __shfl_down(flags, off);
     if (lane == 0) {
-        st.ptr = ptr + L;
-        state[slot] = st;
-        over[ch] = of;
+        DitherState<T> out = st;
+        out.ptr = ptr + L;
+        out.s0 = s0; out.s1 = s1;
+        state[slot] = out;
+        over[ch].n_overflows = n_over;
+        over[ch].intlargest = intlargest;
+        over[ch].largest = largest;
         if (flags) atomicOr(status, flags);
     }
 }
