@@ -122,6 +122,7 @@ def lib():
     L.bfhip_engine_read_ring_slot.argtypes = [vp, ci, ci, vp]
     ull = C.POINTER(C.c_ulonglong)
     L.bfhip_engine_prewarm.argtypes = [vp]
+    L.bfhip_engine_set_powersave.argtypes = [vp, cd]
     L.bfhip_engine_rt_begin.argtypes = [vp, ci]
     L.bfhip_engine_rt_end.argtypes = [vp]
     L.bfhip_engine_rt_buffer.restype = vp
@@ -210,6 +211,9 @@ class Engine:
             self.in_bytes = nbytes
         else:
             self.out_bytes = nbytes
+
+    def set_powersave(self, analog_powersave):
+        _check(lib().bfhip_engine_set_powersave(self.h, analog_powersave))
 
     def set_safety_limit(self, v):
         _check(lib().bfhip_engine_set_safety_limit(self.h, v))

@@ -163,6 +163,10 @@ struct bfhip_engine {
     int n_ch[2] = {0, 0};
     std::vector<bfhip_format> fmt[2];
     double safety_limit = 0.0;
+    // `powersave:` (bfconf.c:1549-1561): 0 off, >= 1 exact-zero windows, < 1 linear noise floor
+    double powersave = 0.0;
+    int *d_ps_flags = nullptr, *d_ps_live = nullptr;
+    double *d_ps_scale = nullptr;
     std::vector<Coeff> coeffs;
     std::vector<Filter> filters;
     bool finalized = false, plan_dirty = true;
@@ -344,6 +348,13 @@ int sync_all(bfhip_engine *e) {
 
 // raise a kernel's dynamic-LDS limit once per (device, kernel, size): the attribute call costs a
 // few microseconds, which is real money in a 35 us block
+inline PowerSave ps_arg(const bfhip_engine *e) {
+    PowerSave ps;
+    ps.thr = e->d_ps_flags ? e->powersave : 0.0;
+    ps.scale = e->d_ps_scale; ps.flags = e->d_ps_flags; ps.live = e->d_ps_live;
+    return ps;
+}
+
 template <typename K> hipError_t allow_lds(K kernel, size_t bytes) {
     static std::mutex mu;
     static std::set<std::tuple<int, const void *, size_t>> done;
@@ -367,7 +378,7 @@ void launch_fft_in(bfhip_engine *e, const uint8_t *raw, int slot, hipError_t *er
     if (*err != hipSuccess) return;
     hipLaunchKernelGGL(k, dim3(e->n_ch[0]), dim3(NT), lds, e->ls, raw, e->d_fmt[0],
                        (T *)e->d_prev, (c2<T> *)e->d_ring, (const c2<T> *)e->d_tw, e->R, slot,
-                       (const BlockState *)e->bs_arg);
+                       (const BlockState *)e->bs_arg, ps_arg(e));
     *err = hipGetLastError();
 }
 
@@ -381,7 +392,7 @@ void launch_fft_in_lo(bfhip_engine *e, const uint8_t *raw, int slot, hipError_t 
     if (*err != hipSuccess) return;
     hipLaunchKernelGGL(k, dim3(e->n_ch[0]), dim3(LO_NT), lds, e->ls, raw, e->d_fmt[0],
                        (T *)e->d_prev, (c2<T> *)e->d_ring, (const c2<T> *)e->d_tw_lo, e->R, slot,
-                       (const BlockState *)e->bs_arg);
+                       (const BlockState *)e->bs_arg, ps_arg(e));
     *err = hipGetLastError();
 }
 
@@ -463,7 +474,7 @@ void launch_io(bfhip_engine *e, const void *z, int first, int count, uint8_t *ra
                        (const c2<T> *)z, first, e->d_fmt[1], e->d_over, (const unsigned char *)e->d_skip_quant,
                        rawout, e->d_timeout ? (T *)e->d_timeout + (size_t)first * e->L : (T *)nullptr,
                        e->safety_limit, e->d_status,
-                       rawin, e->d_fmt[0], (T *)e->d_prev, (c2<T> *)e->d_ring, e->R, slot, (const c2<T> *)e->d_tw);
+                       rawin, e->d_fmt[0], (T *)e->d_prev, (c2<T> *)e->d_ring, e->R, slot, (const c2<T> *)e->d_tw, ps_arg(e));
     *err = hipGetLastError();
 }
 
@@ -785,6 +796,7 @@ int build_plan_t(bfhip_engine *e) {
                 ne.ring = needY ? Yptr(fi) : ring;
                 ne.R = needY ? 1 : (owner ? e->N : e->R);
                 ne.delay = needY ? 0 : rdelay;
+                ne.live = (!needY && !owner && e->d_ps_live) ? e->d_ps_live + ring_id : nullptr;
                 for (int q = 0; q < OG; q++) ne.term[q].kind = TERM_NONE;
                 per_group[g].push_back(ne);
                 ei = (int)per_group[g].size() - 1;
@@ -1531,7 +1543,8 @@ void bfhip_engine_destroy(bfhip_engine *e) {
                     e->d_bad, e->d_Zp, e->d_entries, e->d_chunks, e->d_rawin, e->d_rawout, e->d_taps,
                     e->d_fring, e->d_Y, e->d_Yold, e->d_evalprev, e->d_jobs,
                     e->d_dither_ch, e->d_dither_state, e->d_dither_table, e->d_randmap, e->d_skip_quant, e->d_timeout,
-                    e->d_big[0], e->d_big[1], e->d_big[2], e->d_tw13, e->d_tw_lo};
+                    e->d_big[0], e->d_big[1], e->d_big[2], e->d_tw13, e->d_tw_lo,
+                    e->d_ps_flags, e->d_ps_live, e->d_ps_scale};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto ev : e->ev) (void)hipEventDestroy(ev);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -1556,6 +1569,14 @@ int bfhip_engine_set_overlap(bfhip_engine *e, int mode) {
 int bfhip_engine_set_safety_limit(bfhip_engine *e, double limit) {
     if (!e) return fail(BFHIP_EINVAL, "null engine");
     e->safety_limit = limit;
+    return BFHIP_OK;
+}
+
+int bfhip_engine_set_powersave(bfhip_engine *e, double analog_powersave) {
+    if (!e) return fail(BFHIP_EINVAL, "null engine");
+    if (e->finalized) return fail(BFHIP_ESTATE, "set_powersave after finalize");
+    if (analog_powersave < 0.0) return fail(BFHIP_EINVAL, "set_powersave: negative noise floor");
+    e->powersave = analog_powersave;
     return BFHIP_OK;
 }
 
@@ -1883,6 +1904,23 @@ int bfhip_engine_finalize(bfhip_engine *e) {
         return fail(BFHIP_ENOMEM, "out of device memory for the spectrum rings");
     HIPCHK(hipMemset(e->d_prev, 0, prev_b));       // bfrun.c:1388: everything starts zeroed
     HIPCHK(hipMemset(e->d_ring, 0, ring_b));
+    if (e->powersave > 0.0) {
+        if (e->big) {
+            // silence would have to be detected across many workgroups; an exact-zero test changes
+            // no sample, so it is simply not applied -- a noise floor does, so it is refused
+            if (e->powersave < 1.0) return fail(BFHIP_EINVAL, "powersave with a noise floor is not supported for filter_length > 8192");
+        } else {
+            std::vector<int> ones((size_t)e->n_ch[0] * e->R, 1);     // the zeroed rings are silence
+            std::vector<double> sc(e->n_ch[0]);
+            for (int c = 0; c < e->n_ch[0]; c++) sc[c] = e->fmt[0][e->v2p[0][c]].scale;
+            HIPCHK(hipMalloc((void **)&e->d_ps_flags, ones.size() * sizeof(int)));
+            HIPCHK(hipMemcpy(e->d_ps_flags, ones.data(), ones.size() * sizeof(int), hipMemcpyHostToDevice));
+            HIPCHK(hipMalloc((void **)&e->d_ps_live, e->n_ch[0] * sizeof(int)));
+            HIPCHK(hipMemset(e->d_ps_live, 0, e->n_ch[0] * sizeof(int)));
+            HIPCHK(hipMalloc((void **)&e->d_ps_scale, sc.size() * sizeof(double)));
+            HIPCHK(hipMemcpy(e->d_ps_scale, sc.data(), sc.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
+    }
     for (int io = 0; io < 2; io++) HIPCHK(hipMalloc((void **)&e->d_fmt[io], e->n_ch[io] * sizeof(DevFormat)));
     { int rs_ = subdelay_setup(e); if (rs_ != BFHIP_OK) return rs_; }
     // channels that share a physical channel: private copies, delay lines, job tables

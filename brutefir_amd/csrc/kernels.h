@@ -57,6 +57,7 @@ template <typename T> struct MacEntry {
                         // 16: the same for the subset `mask` of the terms, the rest empty;
                         // 2 + j: term j is the only one; 0: generic per-term path
     int mask;           // dense == 16: bit j set = term j is active
+    const int *live;    // powersave: how many of the ring's slots hold a non-silent block (null: n/a)
     MacTerm<T> term[OG];
 };
 
@@ -197,6 +198,18 @@ __device__ __forceinline__ void tangle(c2<T> a, c2<T> bconj, c2<T> w, c2<T> &zk,
     zlk = mk<T>(e.x + o.y, -e.y + o.x);
 }
 
+// `powersave:` on the device.  thr = 0: off.  thr >= 1: a 2L window whose reals are all zero bits
+// is silent (memiszero, bfrun.c:696-719); thr < 1: a window with scale * max|x| < thr is silent
+// and counts as zero (test_silent, :721-771).  A silent window's spectrum is zero (:1541-1553);
+// flags[ch * R + slot] remembers it and live[ch] counts the non-silent slots of the ring so that
+// the MAC can skip inputs that have been silent for a whole filter length.
+struct PowerSave {
+    double thr;
+    const double *scale;    // [n_in] sf.scale of the input's sample format
+    int *flags;             // [n_in][R], 1 = silent
+    int *live;              // [n_in]
+};
+
 // One workgroup per input channel.  Window = [previous L samples | new L samples]
 // (fftw_convolver.c:181-193); z[n] = x[2n] + i x[2n+1]; complex FFT; untangle; write the
 // packed spectrum into ring slot `slot` of that channel.  All global loads (twiddles,
@@ -206,7 +219,7 @@ __device__ __forceinline__ void
 fft_in_body(int ch, unsigned char *smem, const uint8_t *__restrict__ raw, const DevFormat *__restrict__ fmt,
             T *__restrict__ prev,            // [n_in][L] last block's samples
             c2<T> *__restrict__ ring,        // [n_in][R][L]
-            const c2<T> *__restrict__ tw, int R, int slot) {
+            const c2<T> *__restrict__ tw, int R, int slot, PowerSave ps) {
     constexpr int L = 1 << LOG2L, NT = NTP;
     constexpr int QP = UT<T, LOG2L, NT>::QP, QU = UT<T, LOG2L, NT>::QU;
     LdsArr<T> s{reinterpret_cast<c2<T> *>(smem)};
@@ -242,6 +255,53 @@ fft_in_body(int ch, unsigned char *smem, const uint8_t *__restrict__ raw, const 
                                load_raw<T>(base + (size_t)(2 * n + 1) * stride, f));
         }
     }
+    c2<T> *out = ring + ((size_t)ch * R + slot) * L;
+    if (ps.thr > 0.0) {                                   // uniform
+        __shared__ T ps_red[16];
+        const bool exact = ps.thr >= 1.0;
+        T m = (T)0;                                        // exact: 1 if any bit is set; else max |x|
+#pragma unroll
+        for (int i = 0; i < QP; i++) {
+            const int n = tid + i * NT;
+            if (L / 2 % NT == 0 || n < L / 2) {
+                const T v4[4] = {old[i].x, old[i].y, cur[i].x, cur[i].y};
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const T v = v4[q];
+                    if (exact) {
+                        bool nz;
+                        if constexpr (sizeof(T) == 4) nz = __float_as_uint(v) != 0u;
+                        else nz = __double_as_longlong(v) != 0ll;
+                        if (nz) m = (T)1;
+                    } else if (v < (T)0) { if (-v > m) m = -v; }
+                    else { if (v > m) m = v; }
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { const T o = __shfl_xor(m, off); m = o > m ? o : m; }
+        if ((tid & 63) == 0) ps_red[tid >> 6] = m;
+        __syncthreads();
+        m = ps_red[0];
+        for (int w = 1; w < NT / 64; w++) m = ps_red[w] > m ? ps_red[w] : m;
+        const bool silent = exact ? (m == (T)0) : !(ps.scale[ch] * (double)m >= ps.thr);
+        if (tid == 0) {
+            const int was = ps.flags[ch * R + slot], now = silent ? 1 : 0;
+            ps.flags[ch * R + slot] = now;
+            if (was != now) ps.live[ch] += was - now;
+        }
+        if (silent) {
+            // the block still becomes "the previous block" of the next window (the reference zeroes
+            // its transform buffer, not the copy kept for the next call: fftw_convolver.c:181-193)
+#pragma unroll
+            for (int i = 0; i < QP; i++) {
+                const int n = tid + i * NT;
+                if (L / 2 % NT == 0 || n < L / 2) pv[n] = cur[i];
+            }
+            for (int k = tid; k < L; k += NT) out[k] = mk<T>((T)0, (T)0);
+            return;
+        }
+    }
     TwRegs<T, LOG2L, NT> twr;
     twr.prefetch(tw);
     c2<T> uw[QU];
@@ -262,7 +322,6 @@ fft_in_body(int ch, unsigned char *smem, const uint8_t *__restrict__ raw, const 
     lds_fft<T, LOG2L, NT, false>(s, twr);
     BF_PROBE(10);
 
-    c2<T> *out = ring + ((size_t)ch * R + slot) * L;
     if (tid == 0) out[0] = mk<T>(s[0].x + s[0].y, s[0].x - s[0].y);
 #pragma unroll
     for (int i = 0; i < QU; i++) {
@@ -281,10 +340,10 @@ template <typename T, int LOG2L, int NTP = fft_threads<T>(LOG2L)>
 __global__ __launch_bounds__(NTP) void
 fft_in_kernel(const uint8_t *__restrict__ raw, const DevFormat *__restrict__ fmt, T *__restrict__ prev,
               c2<T> *__restrict__ ring, const c2<T> *__restrict__ tw, int R, int slot,
-              const BlockState *__restrict__ bs) {
+              const BlockState *__restrict__ bs, PowerSave ps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (bs) slot = (int)(bs->t % (unsigned int)R);
-    fft_in_body<T, LOG2L, NTP>(blockIdx.x, smem, raw, fmt, prev, ring, tw, R, slot);
+    fft_in_body<T, LOG2L, NTP>(blockIdx.x, smem, raw, fmt, prev, ring, tw, R, slot, ps);
 }
 
 // ------------------------------------------------------------------ K7: taps -> coefficient partition
@@ -445,6 +504,9 @@ mac_xbar_kernel(const MacEntry<T> *__restrict__ entries, const ChunkRange *__res
         const int p0 = E->p0;
         int maxP = E->maxP;
         if (maxP > age - delay) maxP = age - delay;     // blocks that exist yet (procblocks)
+        // powersave (bfrun.c:1541-1553, 1694-1770): every block this input still has in its ring
+        // is silence -> nothing to add, nothing to read
+        if (E->live != nullptr && *E->live == 0) continue;
         if (E->dense == 1 || E->dense == 16) {
             const unsigned int mask = E->dense == 1 ? 0xffu : (unsigned int)E->mask;
             // The crossbar case: OG coefficient terms of equal length (or, for the last group of
@@ -1153,13 +1215,13 @@ io_kernel(int n_k3,
           DevOverflow *__restrict__ over, const unsigned char *__restrict__ skip_quant,
           uint8_t *__restrict__ rawout, T *__restrict__ timeout, double safety_limit, int *__restrict__ status,
           const uint8_t *__restrict__ rawin, const DevFormat *__restrict__ fmt_in, T *__restrict__ prev,
-          c2<T> *__restrict__ ring, int R, int slot, const c2<T> *__restrict__ tw) {
+          c2<T> *__restrict__ ring, int R, int slot, const c2<T> *__restrict__ tw, PowerSave ps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if ((int)blockIdx.x < n_k3)
         ifft_out_body<T, LOG2L>(blockIdx.x, smem, Zp, 0, 1, first_channel, fmt_out, over, skip_quant,
                                 rawout, timeout, tw, safety_limit, status);
     else
-        fft_in_body<T, LOG2L>((int)blockIdx.x - n_k3, smem, rawin, fmt_in, prev, ring, tw, R, slot);
+        fft_in_body<T, LOG2L>((int)blockIdx.x - n_k3, smem, rawin, fmt_in, prev, ring, tw, R, slot, ps);
 }
 
 // ------------------------------------------------------------------ N:1 virtual channels: delay, mute, mix

@@ -114,6 +114,12 @@ int bfhip_engine_enable_subdelay(bfhip_engine *e, int sdf_length, double kaiser_
 int bfhip_engine_set_subdelay(bfhip_engine *e, int io, int virt_channel, int subdelay);
 /* bfconf->safety_limit (linear, 0 = off), bfconf.c "safety_limit" setting */
 int bfhip_engine_set_safety_limit(bfhip_engine *e, double limit);
+/* `powersave:` (bfconf.c:1549-1561, bfrun.c:721-771, 1541-1553).  0 = off (default); >= 1.0 =
+   `powersave: true`: a 2L input window that is exactly zero is not transformed and inputs that
+   have been silent for a whole filter length are skipped by the MAC -- no sample changes;
+   10^(dB/20) < 1.0 = `powersave: <dB>`: windows below that level (full scale = 1.0) count as
+   silence and are made zero, like the reference does.  Before finalize. */
+int bfhip_engine_set_powersave(bfhip_engine *e, double analog_powersave);
 /* outputs to dither + dither_init() parameters (dither.c:75-139, bfconf.c:3170-3230) */
 int bfhip_engine_enable_dither(bfhip_engine *e, const int out_channels[], int n,
                                int sample_rate, int max_size);

@@ -669,6 +669,7 @@ struct bfo_engine {
     int *dither_ch;                 /* per output: dither state index or -1 */
     bfo_overflow *overflow;
     double safety_limit;
+    double powersave;              /* 0 = off, >= 1.0 exact zero test, else linear noise floor */
     int n_filters, n_coeffs;
     ofilter *f;
     ocoeff *co;
@@ -798,6 +799,42 @@ bfo_engine_set_format(bfo_engine *e, int io, int ch, const bfo_format *bf)
         }
     }
 }
+
+/* test_silent, bfrun.c:721-771 (n_reals = the whole 2L window).  analog_powersave >= 1.0: the
+   window is silent iff every byte is zero (memiszero, :696-719: -0.0 is NOT zero); else iff
+   scale * max|x| < analog_powersave, and then the window is made truly zero. */
+static int
+test_silent(void *buf, int n_reals, int rs, double analog_powersave, double scale)
+{
+    int n;
+    double dmax;
+    if (analog_powersave >= 1.0) {
+        const uint8_t *b = buf;
+        uint8_t acc = 0;
+        size_t i;
+        for (i = 0; i < (size_t)n_reals * rs; i++) acc |= b[i];
+        return acc == 0;
+    }
+    if (rs == 4) {
+        float fmax = 0;
+        for (n = 0; n < n_reals; n++) {
+            const float v = ((float *)buf)[n];
+            if (v < 0) { if (-v > fmax) fmax = -v; } else { if (v > fmax) fmax = v; }
+        }
+        dmax = fmax;
+    } else {
+        dmax = 0;
+        for (n = 0; n < n_reals; n++) {
+            const double v = ((double *)buf)[n];
+            if (v < 0) { if (-v > dmax) dmax = -v; } else { if (v > dmax) dmax = v; }
+        }
+    }
+    if (scale * dmax >= analog_powersave) return 0;
+    memset(buf, 0, (size_t)n_reals * rs);
+    return 1;
+}
+
+void bfo_engine_set_powersave(bfo_engine *e, double analog_powersave) { e->powersave = analog_powersave; }
 
 void
 bfo_engine_set_safety_limit(bfo_engine *e, double limit)
@@ -1009,7 +1046,14 @@ bfo_engine_block(bfo_engine *e, const void *rawin, void *rawout)
             apply_subdelay(e, 0, n, e->in_time[!cur][n]);
             memcpy((uint8_t *)e->in_time[cur][n] + halfb, e->in_time[!cur][n], halfb);
         }
-        bfo_time2freq(c, e->in_time[cur][n], e->in_freq[n]);
+        /* bfrun.c:1541-1553 + test_silent (:721-771): with powersave a silent 2L window is made
+           truly zero and its spectrum is zero instead of transformed */
+        if (e->powersave > 0.0 &&
+            test_silent(e->in_time[cur][n], 2 * e->L, e->rs, e->powersave, e->fmt[0][e->v2p[0][n]].scale)) {
+            memset(e->in_freq[n], 0, (size_t)2 * e->L * e->rs);
+        } else {
+            bfo_time2freq(c, e->in_time[cur][n], e->in_freq[n]);
+        }
     }
 
     /* bfrun.c:1566-1844: every filter, in order */

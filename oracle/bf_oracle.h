@@ -113,6 +113,9 @@ bfo_engine *bfo_engine_new(int length, int n_blocks, int realsize, int n_in, int
 void bfo_engine_free(bfo_engine *e);
 void bfo_engine_set_format(bfo_engine *e, int io, int channel, const bfo_format *bf);
 void bfo_engine_set_safety_limit(bfo_engine *e, double limit);
+/* `powersave:` (bfconf.c:1549-1561): 0 = off; >= 1.0 = `true` (windows that are exactly zero);
+   10^(dB/20) < 1.0 = noise floor in full-scale units (bfrun.c:721-771, 1541-1553) */
+void bfo_engine_set_powersave(bfo_engine *e, double analog_powersave);
 /* bfconf.c:3170-3230 decides which outputs dither; here the caller says which */
 int bfo_engine_enable_dither(bfo_engine *e, const int out_channels[], int n,
                              int sample_rate, int max_size);

@@ -113,6 +113,7 @@ def lib():
         L.bfo_engine_free.argtypes = [vp]
         L.bfo_engine_set_format.argtypes = [vp, ci, ci, C.POINTER(Format)]
         L.bfo_engine_set_safety_limit.argtypes = [vp, cd]
+        L.bfo_engine_set_powersave.argtypes = [vp, cd]
         L.bfo_engine_enable_dither.argtypes = [vp, C.POINTER(ci), ci, ci, ci]
         L.bfo_engine_map_channels.argtypes = [vp, ci, ci, C.POINTER(ci)]
         for f in ("bfo_engine_set_delay", "bfo_engine_set_maxdelay", "bfo_engine_set_mute"):
@@ -274,6 +275,9 @@ class Engine:
             self.set_format(io, c, f)
         if io == 1:
             self.out_bytes = n * self.L * SAMPLE_FORMATS[name][0]
+
+    def set_powersave(self, analog_powersave):
+        lib().bfo_engine_set_powersave(self.h, analog_powersave)
 
     def set_safety_limit(self, v):
         lib().bfo_engine_set_safety_limit(self.h, v)

@@ -486,3 +486,43 @@ def test_prewarm_changes_cost_not_results(hip):
         assert sa == sb and np.array_equal(ra, rb), k
     with pytest.raises(hip.BfhipError, match="already"):
         b.prewarm()
+
+
+@pytest.mark.parametrize("rs", [4, 8])
+@pytest.mark.parametrize("mode", ["exact", "floor"])
+def test_powersave(hip, rs, mode):
+    """`powersave: true` (exact-zero windows) changes no sample; `powersave: <dB>` makes windows
+    below the noise floor silence (test_silent, bfrun.c:721-771).  Inputs go silent, come back,
+    hover around the floor; one input never carries anything (its MAC entries are skipped)."""
+    L, N, I, O = 128, 4, 3, 2
+    coeffs = [(_ir(300 + k, L * N, I), 1.0, 0) for k in range(I * O)]
+    filters = [dict(in_ch=[i], out_ch=[o], coeff=o * I + i, delayblocks=i % 2) for o in range(O) for i in range(I)]
+    filters.append(dict(in_ch=[0, 1], in_scale=[0.5, 0.5], out_ch=[0], coeff=0))        # a private-ring filter
+    spec = _spec(L, N, rs, I, O, filters, coeffs, infmt="S16_LE")
+    thr = 1.0 if mode == "exact" else 10 ** (-50 / 20)
+
+    class PS:
+        def __init__(self, cls):
+            self.cls = cls
+
+        def __call__(self, *a, **k):
+            e = self.cls(*a, **k)
+            e.set_powersave(thr)
+            return e
+    ge, oe = cases.build(PS(hip.Engine), spec), cases.build(PS(bo.Engine), spec)
+    plain = cases.build(bo.Engine, spec)
+    rng = np.random.default_rng(5)
+    amps = [3000, 3000, 0, 0, 0, 0, 0, 0, 40, 40, 200, 0, 3000, 0, 0, 0, 0, 0, 0, 3000]
+    for b, a in enumerate(amps):
+        x = np.zeros((L, I), np.int16)
+        x[:, 0] = (rng.standard_normal(L) * a).astype(np.int16)
+        x[:, 1] = (rng.standard_normal(L) * (a // 2)).astype(np.int16)          # input 2 stays silent
+        gs, g = ge.block(x)
+        os_, o = oe.block(x)
+        ps_, p = plain.block(x)
+        assert gs == os_ == 0
+        gsamp, osamp, psamp = (cases.samples(v, spec["outfmt"]) for v in (g, o, p))
+        if mode == "exact":
+            assert np.array_equal(osamp, psamp), b                  # the oracle: transparent
+        scale = max(np.abs(osamp).max(), 1e-3)
+        assert np.abs(gsamp - osamp).max() <= (1e-5 if rs == 4 else 1e-12) * scale * 4, b

@@ -44,10 +44,10 @@ void run(int n_ch, int spacing_is_interleaved) {
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int iters = 50;
-    for (int w = 0; w < 5; w++) hipLaunchKernelGGL(k, dim3(n_ch), dim3(NT), lds, 0, d_raw, d_fmt, d_prev, d_ring, d_tw, R, w % R, (const BlockState *)nullptr);
+    for (int w = 0; w < 5; w++) hipLaunchKernelGGL(k, dim3(n_ch), dim3(NT), lds, 0, d_raw, d_fmt, d_prev, d_ring, d_tw, R, w % R, (const BlockState *)nullptr, PowerSave{0.0, nullptr, nullptr, nullptr});
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, 0));
-    for (int w = 0; w < iters; w++) hipLaunchKernelGGL(k, dim3(n_ch), dim3(NT), lds, 0, d_raw, d_fmt, d_prev, d_ring, d_tw, R, w % R, (const BlockState *)nullptr);
+    for (int w = 0; w < iters; w++) hipLaunchKernelGGL(k, dim3(n_ch), dim3(NT), lds, 0, d_raw, d_fmt, d_prev, d_ring, d_tw, R, w % R, (const BlockState *)nullptr, PowerSave{0.0, nullptr, nullptr, nullptr});
     CK(hipEventRecord(e1, 0));
     CK(hipDeviceSynchronize());
     float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
