@@ -87,9 +87,26 @@ def _apply(eng, evs):
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("BFHIP_FUZZ_SEEDS", "100"))))
 def test_random_network_and_control_sequence(hip, seed):
     spec, n_blocks, events = _network(seed)
-    ge, oe = cases.build(hip.Engine, spec), cases.build(bo.Engine, spec)
+    prng = np.random.default_rng(31337 + seed)
+    powersave = float(prng.choice([0.0, 0.0, 1.0, 10 ** (-60 / 20)]))       # off / `true` / -60 dB
+
+    def with_ps(cls):
+        def make(*a, **k):
+            e = cls(*a, **k)
+            if powersave:
+                e.set_powersave(powersave)
+            return e
+        return make
+    ge, oe = cases.build(with_ps(hip.Engine), spec), cases.build(with_ps(bo.Engine), spec)
     tol = 3e-5 if spec["rs"] == 4 else 1e-11
     blocks = cases.raw_blocks(seed, n_blocks, spec["L"], spec["n_in"], spec["infmt"], amplitude=0.2)
+    for blk in blocks:                                   # stretches of silence and of near silence
+        for ch in range(spec["n_in"]):
+            u = prng.random()
+            if u < 0.25:
+                blk[:, ch] = 0
+            elif u < 0.35 and not spec["infmt"].startswith("FLOAT"):
+                blk[:, ch] = (blk[:, ch].astype(np.int64) >> 12).astype(blk.dtype)
     scale = 0.0
     for b, blk in enumerate(blocks):
         _apply(ge, events.get(b, []))
