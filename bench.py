@@ -60,10 +60,9 @@ def synth_raw_blocks(torch, n, L, n_ch, device, seed=1234):
     return torch.clamp(torch.round(x * 8388608.0), -8388608, 8388607).to(torch.int32).contiguous()
 
 
-def cpu_baseline(wl, seconds_budget=25.0):
-    """The oracle (a single-threaded port of the reference path, oracle/bf_oracle.c) timed on
-    this box's host cores on a bounded sample of the same workload: a few of the outputs,
-    all inputs, all partitions, a few blocks after the rings are full."""
+def _cpu_worker(args):
+    """one host core's share of the CPU baseline (runs in a spawned process: no GPU in here)"""
+    wl, seed, seconds = args
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import bforacle as bo
     I, O, L, N, rs, fmt = wl
@@ -74,7 +73,7 @@ def cpu_baseline(wl, seconds_budget=25.0):
     for c, f in enumerate(bo.interleaved_formats(fmt, o_s)):
         e.set_format(1, c, f)
     e.out_bytes = o_s * L * bo.SAMPLE_FORMATS[fmt][0]
-    rng = np.random.default_rng(99)
+    rng = np.random.default_rng(99 + seed)
     h = rng.standard_normal(L * N).astype(np.float32 if rs == 4 else np.float64)
     h *= np.exp(-np.arange(L * N) / (L * N / 6.0))
     h /= np.abs(h).sum() * I
@@ -94,16 +93,54 @@ def cpu_baseline(wl, seconds_budget=25.0):
         e.block(raw)
         n += 1
         el = time.time() - t1
-        if el > seconds_budget * 0.4 or n >= 2000:          # ~10 s of timed CPU work
+        if el > seconds or n >= 2000:
             break
-    # per-output cost measured on o_s outputs; the workload's input FFTs are shared by all O
-    sps = o_s * L * n / el
+    return o_s * L * n / el, n, t1 - t0
+
+
+def cpu_baseline(wl, seconds=10.0):
+    """The oracle (a port of the reference path, oracle/bf_oracle.c) timed on this box's host
+    cores on a bounded sample of the same workload: per core a few of the outputs, all inputs,
+    all partitions, steady-state blocks after the rings are full.  One process per core, the way
+    the reference spreads its filters over `n_processes` (bfconf.c:2227-2318); the single-core
+    figure is reported beside the aggregate."""
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import bforacle as bo
+    bo.lib()                                          # build once, before the workers race for it
+    I, O, L, N, rs, fmt = wl
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16, max(1, O // 2)))
+    single = _cpu_worker((wl, 0, seconds / 2))
+    agg, per = single[0], [single]
+    if cores > 1:
+        # plain child processes of this very script (no GPU in them), bounded by a timeout
+        name = [k for k, v in WORKLOADS.items() if v == wl][0]
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(k),
+                                   "--workload", name, "--cpu-seconds", str(seconds)],
+                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+                 for k in range(cores)]
+        got = []
+        for pr in procs:
+            try:
+                out, _ = pr.communicate(timeout=seconds + 120)
+                got.append(tuple(json.loads(out.strip().splitlines()[-1])))
+            except Exception:                         # noqa: BLE001
+                pr.kill()
+        if len(got) == cores:
+            per, agg = got, sum(g[0] for g in got)
+        else:
+            cores = 1                                 # report what was measured
     ref_loop = reference_hot_loop(bo, L, rs, I, N)
-    return {"value": sps, "unit": "samples/s", "cores": 1, "kind": "port",
+    return {"value": agg, "unit": "samples/s", "cores": cores, "kind": "port",
+            "single_core_value": single[0],
             "reference_hot_loop": ref_loop,
-            "sample": "%d of %d outputs x %d inputs x %d partitions of %d taps, %d steady-state "
-                      "blocks (input FFTs included), gcc -O2, setup+warm-up %.1fs"
-                      % (o_s, O, I, N, L, n, t1 - t0)}
+            "sample": "per core: %d of %d outputs x %d inputs x %d partitions of %d taps, %d-%d steady-state "
+                      "blocks in %.0f s (input FFTs included), gcc -O2, %d worker processes"
+                      % (min(O, 2), O, I, N, L, min(p[1] for p in per), max(p[1] for p in per), seconds, cores)}
 
 
 def reference_hot_loop(bo, L, rs, I, N, seconds=3.0):
@@ -149,7 +186,13 @@ def main():
     ap.add_argument("--host-io", action="store_true",
                     help="time bfhip_engine_block() with HOST raw buffers (PCIe both ways and a "
                          "sync per block included) -- informative, never the headline value")
+    ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_worker is not None:
+        # one core's share of the CPU baseline (a child of cpu_baseline()): oracle only, no GPU
+        print(json.dumps(_cpu_worker((WORKLOADS[args.workload], args.cpu_worker, args.cpu_seconds))), flush=True)
+        return
 
     import torch
     import brutefir_amd as bf
