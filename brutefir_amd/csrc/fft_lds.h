@@ -109,8 +109,9 @@ constexpr int tw_total(int log2l, int nt, int log2ns) {
 // made the kernels spill; or a narrow workgroup with many butterflies per thread): nothing is
 // held in registers, every pass reads its twiddles from the thread-ordered table when it needs
 // them -- still one coalesced load per value.
-template <typename T, int LOG2L, int NT> struct TwRegs {
-    static constexpr bool LAZY = (size_t)tw_total(LOG2L, NT, 0) * sizeof(c2<T>) > 256;     // > 64 VGPRs
+template <typename T, int LOG2L, int NT, bool FORCE_LAZY = false> struct TwRegs {
+    // FORCE_LAZY: kernels that run several transforms and keep other state across them
+    static constexpr bool LAZY = FORCE_LAZY || (size_t)tw_total(LOG2L, NT, 0) * sizeof(c2<T>) > 256;     // > 64 VGPRs
     static constexpr int N = (LAZY || tw_total(LOG2L, NT, 0) == 0) ? 1 : tw_total(LOG2L, NT, 0);
     c2<T> r[N];
     const c2<T> *g;                 // thread-ordered table, this thread's column
@@ -142,8 +143,8 @@ template <typename T, int LOG2L, int NT> struct TwRegs {
 };
 
 // one Stockham pass on the padded LDS array with prefetched twiddles
-template <typename T, int LOG2L, int NT, bool INV, int LOG2NS, int OFF>
-__device__ __forceinline__ void fft_pass(LdsArr<T> s, const TwRegs<T, LOG2L, NT> &tw) {
+template <typename T, int LOG2L, int NT, bool INV, int LOG2NS, int OFF, typename TW>
+__device__ __forceinline__ void fft_pass(LdsArr<T> s, const TW &tw) {
     constexpr int LOG2R = pass_log2r(LOG2L, LOG2NS);
     constexpr int L = 1 << LOG2L, R = 1 << LOG2R, Ns = 1 << LOG2NS, TT = L / R;
     constexpr int B = pass_b(LOG2L, NT, LOG2NS), NTW = pass_ntw(LOG2L, LOG2NS);
@@ -189,8 +190,8 @@ __device__ __forceinline__ void fft_pass(LdsArr<T> s, const TwRegs<T, LOG2L, NT>
     __syncthreads();
 }
 
-template <typename T, int LOG2L, int NT, bool INV, int LOG2NS, int OFF>
-__device__ __forceinline__ void fft_passes(LdsArr<T> s, const TwRegs<T, LOG2L, NT> &tw) {
+template <typename T, int LOG2L, int NT, bool INV, int LOG2NS, int OFF, typename TW>
+__device__ __forceinline__ void fft_passes(LdsArr<T> s, const TW &tw) {
     if constexpr (LOG2NS < LOG2L) {
         constexpr int LOG2R = pass_log2r(LOG2L, LOG2NS);
         fft_pass<T, LOG2L, NT, INV, LOG2NS, OFF>(s, tw);
@@ -201,8 +202,8 @@ __device__ __forceinline__ void fft_passes(LdsArr<T> s, const TwRegs<T, LOG2L, N
 
 // Complex FFT of the L values in s (padded LDS array), in place, natural order in and out.
 // The caller has synchronised after filling s; on return all threads see the result.
-template <typename T, int LOG2L, int NT, bool INV>
-__device__ __forceinline__ void lds_fft(LdsArr<T> s, const TwRegs<T, LOG2L, NT> &tw) {
+template <typename T, int LOG2L, int NT, bool INV, typename TW>
+__device__ __forceinline__ void lds_fft(LdsArr<T> s, const TW &tw) {
     fft_passes<T, LOG2L, NT, INV, 0, 0>(s, tw);
 }
 

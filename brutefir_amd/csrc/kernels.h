@@ -762,7 +762,7 @@ ring_fill_kernel(const FillJob<T> *__restrict__ jobs, const MixSrc<T> *__restric
     c2<T> *dst = job.ring + (size_t)((t + (unsigned int)job.delay) % (unsigned int)N) * L;
     const MixSrc<T> *in = src + job.in_off;
     const MixSrc<T> *up = src + job.up_off;
-    TwRegs<T, LOG2L, NT> twr;
+    TwRegs<T, LOG2L, NT, true> twr;
     c2<T> uw[QU];
 #pragma unroll
     for (int i = 0; i < QU; i++) { const int k = 1 + tid + i * NT; uw[i] = tw[k <= L / 2 ? k : 0]; }
@@ -941,7 +941,7 @@ crossfade_kernel(const FadeJob<T> *__restrict__ jobs, const c2<T> *__restrict__ 
     LdsArr<T> s{reinterpret_cast<c2<T> *>(smem)};
     const int tid = threadIdx.x;
     const FadeJob<T> job = jobs[blockIdx.x];
-    TwRegs<T, LOG2L, NT> twr;
+    TwRegs<T, LOG2L, NT, true> twr;                  // three transforms and the old result live at once
     twr.prefetch(tw);
     c2<T> uw[QU];
 #pragma unroll
