@@ -260,6 +260,7 @@ struct bfhip_engine {
     // HP-TPDF dither (dither.c, dither.h)
     std::vector<int> dither_channels;      // output channel of each dither slot (virtual, ascending, after finalize)
     std::vector<int> dither_rank;          // its rank among the dithered PHYSICAL outputs: where its table walk starts
+    std::vector<char> dither_late;         // slot is the head of a shared / sub-sample-filtered output: dithered after the mix
     std::vector<int8_t> dither_table;
     int dither_spacing = 0;
     int *d_dither_ch = nullptr;
@@ -411,21 +412,24 @@ void launch_coeff_prep(bfhip_engine *e, const void *taps, int n_taps, double sca
 
 // the HP-TPDF pass over the channels of [first, first+count) that dither (after K3)
 template <typename T>
-void launch_dither(bfhip_engine *e, int first, int count, uint8_t *raw, hipError_t *err) {
+void launch_dither(bfhip_engine *e, int first, int count, uint8_t *raw, hipError_t *err, bool late = false) {
     if (e->dither_channels.empty()) return;
-    // dither slots whose channel lies in [first, first+count): the slots are sorted by channel
-    int s0 = 0, s1 = 0;
-    for (size_t i = 0; i < e->dither_channels.size(); i++) {
-        if (e->dither_channels[i] < first) s0 = (int)i + 1;
-        if (e->dither_channels[i] < first + count) s1 = (int)i + 1;
-    }
-    if (s1 > s0) {
+    // dither slots whose channel lies in [first, first+count) (the slots are sorted by channel), in
+    // runs of the requested phase: straight after K3, or after the N:1 mix / sub-sample filter
+    const int n = (int)e->dither_channels.size();
+    for (int s0 = 0; s0 < n;) {
+        const bool in = e->dither_channels[s0] >= first && e->dither_channels[s0] < first + count &&
+                        (bool)e->dither_late[s0] == late;
+        if (!in) { s0++; continue; }
+        int s1 = s0 + 1;
+        while (s1 < n && e->dither_channels[s1] < first + count && (bool)e->dither_late[s1] == late) s1++;
         hipLaunchKernelGGL(dither_kernel<T>, dim3(s1 - s0), dim3(64), 0, e->ls,
                            (const T *)e->d_timeout, (const int *)e->d_dither_ch + s0,
                            (DitherState<T> *)e->d_dither_state + s0, (const int8_t *)e->d_dither_table,
                            (int)e->dither_table.size(), (const T *)e->d_randmap + 256,
                            e->d_fmt[1], e->d_over, raw, e->L, e->safety_limit, e->d_status);
-        *err = hipGetLastError();
+        if ((*err = hipGetLastError()) != hipSuccess) return;
+        s0 = s1;
     }
 }
 
@@ -1154,7 +1158,9 @@ int do_vout(bfhip_engine *e, void *rawout_dev) {
     std::vector<ByteOp> ops;
     for (auto &g : e->vout_groups) {
         VOutJob j;
-        j.first_member = (int)mem.size(); j.n_members = (int)g.size(); j.fmt_channel = g[0]; j.pad = 0;
+        j.first_member = (int)mem.size(); j.n_members = (int)g.size(); j.fmt_channel = g[0]; j.dither = 0;
+        for (size_t d = 0; d < e->dither_channels.size(); d++)
+            if (e->dither_channels[d] == g[0] && e->dither_late[d]) j.dither = 1;
         for (int v : g) {
             VOutMember m;
             m.channel = v; m.muted = e->vmuted[1][v]; m.ops_off = (int)ops.size();
@@ -1181,6 +1187,17 @@ int do_vout(bfhip_engine *e, void *rawout_dev) {
                            (const VOutJob *)dev, (const VOutMember *)(dev + jb), (const ByteOp *)(dev + jb + mb),
                            (double *)e->d_timeout, e->d_fmt[1], e->d_over, (uint8_t *)rawout_dev, e->L, e->safety_limit, e->d_status);
     HIPCHK(hipGetLastError());
+    bool any_late = false;
+    for (char c : e->dither_late) any_late = any_late || c;
+    if (any_late) {
+        hipError_t err = hipSuccess;
+        if (e->rs == 4) launch_dither<float>(e, 0, e->n_ch[1], (uint8_t *)rawout_dev, &err, true);
+        else launch_dither<double>(e, 0, e->n_ch[1], (uint8_t *)rawout_dev, &err, true);
+        if (err != hipSuccess) return fail(BFHIP_EHIP, "dither launch: %s", hipGetErrorString(err));
+        hipLaunchKernelGGL(vout_spread_overflow_kernel<0>, dim3((unsigned)jobs.size()), dim3(64), 0, e->ls,
+                           (const VOutJob *)dev, (const VOutMember *)(dev + jb), e->d_over);
+        HIPCHK(hipGetLastError());
+    }
     return BFHIP_OK;
 }
 
@@ -1948,15 +1965,20 @@ int bfhip_engine_finalize(bfhip_engine *e) {
             for (size_t i = 0; i < e->dither_channels.size(); i++) {
                 const int c = e->dither_channels[i];
                 if (c < 0 || c >= e->n_phys[1]) return fail(BFHIP_EINVAL, "dither: output %d does not exist", c);
-                if (e->n_vpp[1][c] != 1) return fail(BFHIP_EINVAL, "dither on outputs that share a physical channel is not supported");
                 int v = 0;
-                while (e->v2p[1][v] != c) v++;
-                if (e->sd_slot[1][v] >= 0) return fail(BFHIP_EINVAL, "dither on an output with a sub-sample delay filter is not supported");
+                while (e->v2p[1][v] != c) v++;          // the first (lowest) virtual channel of the physical one
                 byvirt.push_back({v, (int)i});
             }
             std::sort(byvirt.begin(), byvirt.end());
-            e->dither_rank.clear();
-            for (size_t j = 0; j < byvirt.size(); j++) { e->dither_channels[j] = byvirt[j].first; e->dither_rank.push_back(byvirt[j].second); }
+            e->dither_rank.clear(); e->dither_late.clear();
+            for (size_t j = 0; j < byvirt.size(); j++) {
+                const int v = byvirt[j].first;
+                e->dither_channels[j] = v;
+                e->dither_rank.push_back(byvirt[j].second);
+                // shared outputs and outputs with a sub-sample filter are requantised by the N:1
+                // pass (bfrun.c:1938-2003): their dither runs on what that pass leaves behind
+                e->dither_late.push_back(e->n_vpp[1][e->v2p[1][v]] > 1 || e->sd_slot[1][v] >= 0);
+            }
         }
         if (e->has_vchan) {
             size_t n_ops_max = 0;

@@ -1281,7 +1281,8 @@ vchan_in_kernel(const VInJob *__restrict__ jobs, const ByteOp *__restrict__ ops,
 // requantised once with the group's shared overflow struct, which is then copied to every
 // member.
 struct VOutMember { int channel, muted, ops_off, n_ops; };
-struct VOutJob { int first_member, n_members, fmt_channel, pad; };
+struct VOutJob { int first_member, n_members, fmt_channel, dither; };   // dither: leave the mix as
+                                                                        // reals in row fmt_channel for the dither pass
 
 template <typename T>
 __global__ __launch_bounds__(256) void
@@ -1322,6 +1323,7 @@ vchan_out_kernel(const VOutJob *__restrict__ jobs, const VOutMember *__restrict_
             filled = true;
         }
         uint8_t tb[8];
+        if (job.dither) { samples[(size_t)job.fmt_channel * L + n] = x; continue; }     // tests + quantiser: dither_kernel
         if (!isfinite(x)) { st |= 1; continue; }
         if (safety_limit != 0.0 && ((double)x < -safety_limit * of.max || (double)x > safety_limit * of.max)) { st |= 2; continue; }
         if (f.isfloat) {
@@ -1363,9 +1365,20 @@ vchan_out_kernel(const VOutJob *__restrict__ jobs, const VOutMember *__restrict_
             st |= red_s[w];
         }
         of.n_overflows += n_over; of.intlargest = intlargest; of.largest = largest;
-        for (int m = 0; m < job.n_members; m++) over[mem[m].channel] = of;     // bfrun.c:1999-2001
+        if (!job.dither) for (int m = 0; m < job.n_members; m++) over[mem[m].channel] = of;     // bfrun.c:1999-2001
         if (st) atomicOr(status, st);
     }
+}
+
+// after the dither pass of a shared output: every member carries the group's overflow struct
+// (bfrun.c:1999-2001)
+template <int UNUSED>
+__global__ void vout_spread_overflow_kernel(const VOutJob *__restrict__ jobs, const VOutMember *__restrict__ members,
+                                            DevOverflow *__restrict__ over) {
+    const VOutJob job = jobs[blockIdx.x];
+    if (!job.dither || threadIdx.x != 0) return;
+    const DevOverflow of = over[job.fmt_channel];
+    for (int m = 0; m < job.n_members; m++) over[members[job.first_member + m].channel] = of;
 }
 
 // ------------------------------------------------------------------ sub-sample delay

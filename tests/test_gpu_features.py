@@ -526,3 +526,52 @@ def test_powersave(hip, rs, mode):
             assert np.array_equal(osamp, psamp), b                  # the oracle: transparent
         scale = max(np.abs(osamp).max(), 1e-3)
         assert np.abs(gsamp - osamp).max() <= (1e-5 if rs == 4 else 1e-12) * scale * 4, b
+
+
+@pytest.mark.parametrize("rs", [4, 8])
+def test_dither_on_shared_and_subsample_filtered_outputs(hip, rs):
+    """the mixed samples of an N:1 output group, and the filtered samples of an output with a
+    sub-sample delay, go through the HP-TPDF quantiser like any other dithered output
+    (bfrun.c:1926-1936, 1992-1997: `bfconf->dither_state[physch]`); float64: bit exact"""
+    L, N = 256, 3
+    coeffs = [(_ir(400 + k, L * N, 2), 1.0, 0) for k in range(4)]
+    filters = [dict(in_ch=[0], out_ch=[0], coeff=0), dict(in_ch=[1], out_ch=[1], coeff=1),
+               dict(in_ch=[0], out_ch=[2], coeff=2, out_scale=[0.5]), dict(in_ch=[1], out_ch=[3], coeff=3)]
+
+    def mk(cls):
+        e = cls(L, N, rs, 2, 4)
+        e.map_channels(1, [0, 1, 0, 2])             # virtual 0 and 2 share physical 0 (not adjacent)
+        e.set_interleaved(0, "S24_4LE")
+        e.set_interleaved_phys(1, "S16_LE", 3)
+        e.enable_subdelay(15)
+        e.set_subdelay(1, 1, 33)                    # physical 1: a 1:1 output with a sub-sample filter
+        for v, d in enumerate([0, 0, 70, 0]):
+            e.set_delay(1, v, d); e.set_maxdelay(1, v, 200)
+        for t, s_, nb in coeffs:
+            e.add_coeff(t, s_, nb)
+        e.enable_dither([0, 1, 2], 44100, 0)        # all three physical outputs
+        for f in filters:
+            e.add_filter(**f)
+        if hasattr(e, "finalize"):
+            e.finalize()
+        return e
+    ge, oe = mk(hip.Engine), mk(bo.Engine)
+    for b, blk in enumerate(cases.raw_blocks(77, 10, L, 2, "S24_4LE", amplitude=0.3)):
+        if b == 5:
+            for eng in (ge, oe):
+                eng.set_mute(1, 2, 1)
+                eng.set_delay(1, 2, 10)
+        gs, g = ge.block(blk)
+        os_, o = oe.block(blk)
+        assert gs == os_ == 0
+        gq = np.frombuffer(g.tobytes(), np.int16).reshape(L, 3).astype(np.int64)
+        oq = np.frombuffer(o.tobytes(), np.int16).reshape(L, 3).astype(np.int64)
+        d = np.abs(gq - oq).max(axis=0)
+        if rs == 8:
+            assert d[0] == 0 and d[2] == 0, (b, d)          # mix and plain: exact
+            assert d[1] <= 1, (b, d)                        # behind the FIR (FFT vs direct sum): 1 LSB
+        else:
+            assert d.max() <= 3, (b, d)
+    for ch in range(4):
+        a, c = ge.overflow(ch), oe.overflow(ch)
+        assert a.n_overflows == c.n_overflows and a.max == c.max

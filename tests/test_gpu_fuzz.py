@@ -318,7 +318,6 @@ def test_random_sample_formats_dither_and_subsample_delays(hip, seed):
                                     out_scale=[float(rng.choice([1.0, -0.5, 2.0]))]))
     dither = [o for o in range(n_out) if not fmts[1][o].startswith("FLOAT") and rng.random() < 0.5]
     sd = [[int(rng.integers(-99, 100)) if use_sd and rng.random() < 0.5 else None for _ in range(n)] for n in (n_in, n_out)]
-    dither = [o for o in dither if sd[1][o] is None]              # not supported together (documented)
     half = int(rng.choice([7, 15, 31]))
 
     def mk(mod):
