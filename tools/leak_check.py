@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""create / use / destroy engines of every flavour a few hundred times and watch the device's free
+memory: a leak shows as a steady drift"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import brutefir_amd as bf  # noqa: E402
+
+
+def free_mib():
+    torch.cuda.synchronize()
+    return torch.cuda.mem_get_info()[0] / 2 ** 20
+
+
+def one(k):
+    rng = np.random.default_rng(k)
+    L = int(rng.choice([64, 256, 8192, 16384]))
+    rs = int(rng.choice([4, 8]))
+    e = bf.Engine(L, 3, rs, 2, 3)
+    e.set_interleaved(0, "S24_4LE")
+    e.set_interleaved(1, "S16_LE")
+    if L <= 8192:
+        e.set_powersave(1.0)
+    h = (rng.standard_normal(L * 3) / 100).astype(np.float32 if rs == 4 else np.float64)
+    c = e.add_coeff(h)
+    e.add_filter(in_ch=[0], out_ch=[0], coeff=c, crossfade=True)
+    e.add_filter(in_ch=[0, 1], out_ch=[1], coeff=c)
+    e.add_filter(in_f=[0], out_ch=[2], coeff=-1)
+    e.enable_dither([0], 44100, 0)
+    e.finalize()
+    x = (rng.standard_normal((L, 2)) * 1e5).astype(np.int32)
+    e.block(x)
+    if L <= 8192:
+        e.rt_begin(k & 1)
+        e.rt_block(x)
+        e.set_coeff(0, -1)
+        e.rt_block(x)
+        e.rt_end()
+    e.close()
+    if k % 7 == 0:
+        nu = bf.Nupc([64, 128, 256], [2, 2, 4], rs, 1, 1)
+        nu.set_interleaved(0, "FLOAT_LE")
+        nu.set_interleaved(1, "FLOAT_LE" if rs == 4 else "FLOAT64_LE")
+        nu.add_filter(0, 0, (rng.standard_normal(1000) / 30).astype(np.float32 if rs == 4 else np.float64))
+        nu.finalize()
+        for _ in range(5):
+            nu.block(rng.standard_normal((64, 1)).astype(np.float32))
+        nu.close()
+
+
+def main():
+    for k in range(20):
+        one(k)
+    base = free_mib()
+    marks = []
+    for k in range(20, 320):
+        one(k)
+        if k % 100 == 19:
+            marks.append(free_mib())
+    print("free MiB after warm-up %.1f, then %s -> drift %.1f MiB over 300 engines" % (base, ["%.1f" % m for m in marks], base - marks[-1]))
+    assert base - marks[-1] < 64, "device memory is leaking"
+
+
+if __name__ == "__main__":
+    main()
