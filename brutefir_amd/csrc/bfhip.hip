@@ -84,6 +84,8 @@ struct DelayLine {
 
     size_t frag() const { return (size_t)F * ss; }
 
+    bool host = false;                 // self test: arena in host memory, moves executed on the host
+
     int init(int fragment, int initdelay, int maxd, int sample_size) {
         F = fragment; ss = sample_size;
         int delay = maxd <= 0 ? initdelay : maxd;                      // delay.c:357-360
@@ -91,8 +93,13 @@ struct DelayLine {
         curdelay = initdelay; maxdelay = maxd;
         n_full_cap = delay > F ? delay / F + 1 : 0;
         const size_t total = (size_t)(n_full_cap + 4) * frag();
-        if (hipMalloc((void **)&arena, total) != hipSuccess) return BFHIP_ENOMEM;
-        if (hipMemset(arena, 0, total) != hipSuccess) return BFHIP_EHIP;
+        if (host) {
+            arena = (uint8_t *)calloc(total, 1);
+            if (!arena) return BFHIP_ENOMEM;
+        } else {
+            if (hipMalloc((void **)&arena, total) != hipSuccess) return BFHIP_ENOMEM;
+            if (hipMemset(arena, 0, total) != hipSuccess) return BFHIP_EHIP;
+        }
         uint8_t *p = arena;
         for (int i = 0; i < n_full_cap; i++) { full.push_back(p); p += frag(); }
         rest = p; p += frag();
@@ -2393,6 +2400,36 @@ int bfhip_engine_rt_stats(const bfhip_engine *e, unsigned long long *graph_block
     if (direct_blocks) *direct_blocks = e->rt.n_direct;
     if (captures) *captures = e->rt.n_capture;
     return BFHIP_OK;
+}
+
+// ---- self test of the host-side delay machine: no device involved ---------------------------
+struct bfhip_selftest_delay { DelayLine dl; };
+
+bfhip_selftest_delay *bfhip_selftest_delay_new(int fragment, int initdelay, int maxdelay, int sample_size) {
+    if (fragment < 1 || sample_size < 1 || initdelay < 0) { fail(BFHIP_EINVAL, "selftest_delay_new: bad argument"); return nullptr; }
+    bfhip_selftest_delay *d = new bfhip_selftest_delay();
+    d->dl.host = true;
+    if (d->dl.init(fragment, initdelay, maxdelay, sample_size) != BFHIP_OK) { delete d; fail(BFHIP_ENOMEM, "selftest_delay_new: out of memory"); return nullptr; }
+    return d;
+}
+
+int bfhip_selftest_delay_update(bfhip_selftest_delay *d, void *buf, int delay) {
+    if (!d || !buf) return fail(BFHIP_EINVAL, "selftest_delay_update: bad argument");
+    std::vector<ByteOp> ops;
+    d->dl.update((uint8_t *)buf, delay, ops);
+    for (const ByteOp &o : ops) {
+        // the device runs every move with one thread per byte: source and destination of a move
+        // must not overlap
+        if (o.src && !(o.src + o.n <= o.dst || o.dst + o.n <= o.src)) return fail(BFHIP_ESTATE, "delay machine emitted an overlapping move");
+        if (o.src) memcpy(o.dst, o.src, o.n); else memset(o.dst, 0, o.n);
+    }
+    return (int)ops.size();
+}
+
+void bfhip_selftest_delay_free(bfhip_selftest_delay *d) {
+    if (!d) return;
+    free(d->dl.arena);
+    delete d;
 }
 
 int bfhip_engine_prewarm(bfhip_engine *e) {

@@ -276,6 +276,17 @@ int bfhip_engine_algorithmic_bytes(bfhip_engine *e, double bytes[2]);
 int bfhip_engine_read_output_spectrum(bfhip_engine *e, int out_channel, void *dst_complex);
 int bfhip_engine_read_ring_slot(bfhip_engine *e, int in_channel, int slot, void *dst_complex);
 
+/* ---- self test (no device) ------------------------------------------------------------------
+ * The integer delay of channels that share a physical channel (delay.c:78-340) is a small machine
+ * of buffer moves whose schedule depends on the delay history; the engine runs that machine on the
+ * host and has the device execute the moves it emits.  These three calls run the same machine
+ * with its buffers in host memory, so that its output can be checked against delay.c without a
+ * GPU (tests/test_abi.py).  update returns the number of moves, or a negative error. */
+typedef struct bfhip_selftest_delay bfhip_selftest_delay;
+bfhip_selftest_delay *bfhip_selftest_delay_new(int fragment, int initdelay, int maxdelay, int sample_size);
+int bfhip_selftest_delay_update(bfhip_selftest_delay *d, void *buf /* fragment * sample_size bytes */, int delay);
+void bfhip_selftest_delay_free(bfhip_selftest_delay *d);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,6 +3,7 @@ calls (there is no GPU here); the error path for a missing device is exercised i
 import ctypes as C
 import glob
 import os
+import sys
 import re
 
 import pytest
@@ -80,3 +81,46 @@ def test_product_never_imports_the_oracle():
         if os.path.isfile(path) and path.endswith((".py", ".h", ".hip", ".cpp", ".c")):
             src = open(path, errors="ignore").read()
             assert "bforacle" not in src and "bf_oracle" not in src and "libbfref" not in src, path
+
+
+def test_host_delay_machine_matches_delay_c_without_a_device():
+    """the engine's host mirror of delay.c's buffer machine (it emits the moves the device then
+    executes) against the oracle's delay, which is bit-exact against the reference's own delay.c
+    (tests/test_oracle_delay.py): random fragment sizes, sample sizes, delay histories across the
+    short / long regimes, unlimited maxdelay"""
+    import ctypes as C
+    import numpy as np
+    import brutefir_amd as bf
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import bforacle as bo
+    L = bf.lib()
+    L.bfhip_selftest_delay_new.restype = C.c_void_p
+    L.bfhip_selftest_delay_new.argtypes = [C.c_int] * 4
+    L.bfhip_selftest_delay_update.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.bfhip_selftest_delay_free.argtypes = [C.c_void_p]
+    O = bo.lib()
+    O.bfo_delay_new.restype = C.c_void_p
+    O.bfo_delay_new.argtypes = [C.c_int] * 4
+    O.bfo_delay_update.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    O.bfo_delay_free.argtypes = [C.c_void_p]
+    for seed in range(60):
+        rng = np.random.default_rng(seed)
+        F = int(rng.choice([16, 64, 128, 256]))
+        ss = int(rng.choice([1, 2, 4, 8]))
+        maxd = int(rng.choice([0, F // 2, F, 3 * F + 5, 10 * F, -1]))
+        lim = 12 * F if maxd < 0 else maxd
+        init = int(rng.integers(0, lim + 1))
+        d = L.bfhip_selftest_delay_new(F, init, maxd, ss)
+        o = O.bfo_delay_new(F, init, maxd, ss)
+        assert d and o
+        delay = init
+        for b in range(40):
+            if rng.random() < 0.3:
+                delay = int(rng.integers(0, lim + 1))
+            x = rng.integers(0, 256, F * ss, dtype=np.uint8)
+            a, c = x.copy(), x.copy()
+            assert L.bfhip_selftest_delay_update(d, a.ctypes.data, delay) >= 0, L.bfhip_last_error()
+            O.bfo_delay_update(o, c.ctypes.data, delay)
+            assert np.array_equal(a, c), (seed, b, F, ss, maxd, init, delay)
+        L.bfhip_selftest_delay_free(d)
+        O.bfo_delay_free(o)
