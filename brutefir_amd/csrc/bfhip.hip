@@ -1898,7 +1898,9 @@ int bfhip_engine_finalize(bfhip_engine *e) {
             const int d = clamp_delay(e, f.delayblocks);
             bytes += (double)cblocks_of(e, f.coeff, d) * e->L * e->csize() * std::max<size_t>(1, f.out_ch.size());
         }
-        e->pipelined = bytes / 6.4e12 < 100e-6;
+        // ... and only while the transforms leave most CUs to the MAC: with hundreds of channels the
+        // FFT workgroups fill the chip themselves (config D, 256 + 256: 0.178 ms piped, 0.168 plain)
+        e->pipelined = bytes / 6.4e12 < 100e-6 && e->n_ch[0] + e->n_ch[1] <= 128;
         // (BFHIP_OVERLAP=2: pipeline a long MAC at L = 8192 too, with K1/K3 in 256-thread workgroups
         // that fit on a CU next to a MAC workgroup -- 224 + 288 VGPRs per lane -- so that the side
         // streams displace nothing.  Measured on config C: the transforms disappear behind the MAC
