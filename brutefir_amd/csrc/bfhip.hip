@@ -173,6 +173,7 @@ struct bfhip_engine {
     // `powersave:` (bfconf.c:1549-1561): 0 off, >= 1 exact-zero windows, < 1 linear noise floor
     double powersave = 0.0;
     int *d_ps_flags = nullptr, *d_ps_live = nullptr;
+    unsigned long long *d_ps_acc = nullptr;    // partition lengths above 8192: [2][n_in] running maxima
     double *d_ps_scale = nullptr;
     std::vector<Coeff> coeffs;
     std::vector<Filter> filters;
@@ -587,12 +588,18 @@ inline dim3 big_grid_half(const bfhip_engine *e, int n_tr) { return dim3((unsign
 template <typename T>
 void launch_fft_in_big(bfhip_engine *e, const uint8_t *raw, int slot, hipError_t *err) {
     const int n = e->n_ch[0];
+    const int parity = (int)(e->blocks_done & 1);
+    const bool ps_on = e->d_ps_flags != nullptr;
     hipLaunchKernelGGL(big_in_pre<T>, big_grid_half(e, n), dim3(256), 0, e->ls, raw, e->d_fmt[0], (T *)e->d_prev,
-                       (c2<T> *)e->d_big[0], e->L);
+                       (c2<T> *)e->d_big[0], e->L, ps_on ? e->d_ps_acc : (unsigned long long *)nullptr, n, parity,
+                       e->powersave >= 1.0 ? 1 : 0);
     big_fft<T>(e, n, false, e->ls, err);
     if (*err != hipSuccess) return;
     hipLaunchKernelGGL(big_untangle<T>, big_grid_half(e, n), dim3(256), 0, e->ls, (const c2<T> *)e->d_big[2],
                        (c2<T> *)e->d_ring + (size_t)slot * e->L, (size_t)e->R * e->L, (const c2<T> *)e->d_tw, e->L, (T)1);
+    if (ps_on)
+        hipLaunchKernelGGL(big_ps_finish<T>, dim3((unsigned)(e->L / 256), (unsigned)n), dim3(256), 0, e->ls,
+                           (const unsigned long long *)e->d_ps_acc, n, parity, ps_arg(e), (c2<T> *)e->d_ring, e->R, slot, e->L);
     *err = hipGetLastError();
 }
 
@@ -1568,7 +1575,7 @@ void bfhip_engine_destroy(bfhip_engine *e) {
                     e->d_fring, e->d_Y, e->d_Yold, e->d_evalprev, e->d_jobs,
                     e->d_dither_ch, e->d_dither_state, e->d_dither_table, e->d_randmap, e->d_skip_quant, e->d_timeout,
                     e->d_big[0], e->d_big[1], e->d_big[2], e->d_tw13, e->d_tw_lo,
-                    e->d_ps_flags, e->d_ps_live, e->d_ps_scale};
+                    e->d_ps_flags, e->d_ps_live, e->d_ps_scale, e->d_ps_acc};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto ev : e->ev) (void)hipEventDestroy(ev);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -1932,10 +1939,10 @@ int bfhip_engine_finalize(bfhip_engine *e) {
     HIPCHK(hipMemset(e->d_ring, 0, ring_b));
     if (e->powersave > 0.0) {
         if (e->big) {
-            // silence would have to be detected across many workgroups; an exact-zero test changes
-            // no sample, so it is simply not applied -- a noise floor does, so it is refused
-            if (e->powersave < 1.0) return fail(BFHIP_EINVAL, "powersave with a noise floor is not supported for filter_length > 8192");
-        } else {
+            HIPCHK(hipMalloc((void **)&e->d_ps_acc, 2 * e->n_ch[0] * sizeof(unsigned long long)));
+            HIPCHK(hipMemset(e->d_ps_acc, 0, 2 * e->n_ch[0] * sizeof(unsigned long long)));
+        }
+        {
             std::vector<int> ones((size_t)e->n_ch[0] * e->R, 1);     // the zeroed rings are silence
             std::vector<double> sc(e->n_ch[0]);
             for (int c = 0; c < e->n_ch[0]; c++) sc[c] = e->fmt[0][e->v2p[0][c]].scale;

@@ -107,21 +107,68 @@ inline hipError_t big_fft_run(const c2<T> *zin, c2<T> *zmid, c2<T> *zout, int lo
 // ---- K1 ------------------------------------------------------------------------------------
 
 // window [previous L | new L] packed as z[n] = x[2n] + i x[2n+1] (fft_in_body's first half)
+// `powersave:` at these lengths: the window of a channel is spread over many workgroups, so the
+// silence test (PowerSave, kernels.h) is an atomic maximum over the samples' bit patterns -- all
+// bits for the exact test (-0.0 counts as non-zero, like memiszero), the magnitude for the noise
+// floor -- into acc[parity][ch]; the other parity's word is cleared for the next block.
 template <typename T>
 __global__ __launch_bounds__(256) void
 big_in_pre(const uint8_t *__restrict__ raw, const DevFormat *__restrict__ fmt, T *__restrict__ prev,
-           c2<T> *__restrict__ zin, int L) {
+           c2<T> *__restrict__ zin, int L, unsigned long long *__restrict__ ps_acc, int n_in, int parity,
+           int ps_exact) {
     const int n = blockIdx.x * 256 + threadIdx.x, ch = blockIdx.y;
-    if (n >= L / 2) return;
-    const DevFormat f = fmt[ch];
-    c2<T> *pv = reinterpret_cast<c2<T> *>(prev + (size_t)ch * L);
-    const uint8_t *base = f.alt ? f.alt : raw + f.byte_offset;
-    const size_t stride = (size_t)f.sample_spacing * f.bytes;
-    const c2<T> cur = mk<T>(load_raw<T>(base + (size_t)(2 * n) * stride, f),
-                            load_raw<T>(base + (size_t)(2 * n + 1) * stride, f));
-    zin[(size_t)ch * L + n] = pv[n];
-    zin[(size_t)ch * L + L / 2 + n] = cur;
-    pv[n] = cur;
+    unsigned long long m = 0;
+    if (n < L / 2) {
+        const DevFormat f = fmt[ch];
+        c2<T> *pv = reinterpret_cast<c2<T> *>(prev + (size_t)ch * L);
+        const uint8_t *base = f.alt ? f.alt : raw + f.byte_offset;
+        const size_t stride = (size_t)f.sample_spacing * f.bytes;
+        const c2<T> cur = mk<T>(load_raw<T>(base + (size_t)(2 * n) * stride, f),
+                                load_raw<T>(base + (size_t)(2 * n + 1) * stride, f));
+        const c2<T> old = pv[n];
+        zin[(size_t)ch * L + n] = old;
+        zin[(size_t)ch * L + L / 2 + n] = cur;
+        pv[n] = cur;
+        if (ps_acc) {
+            const T v4[4] = {old.x, old.y, cur.x, cur.y};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                unsigned long long b;
+                if constexpr (sizeof(T) == 4) b = __float_as_uint(v4[q]) & (ps_exact ? 0xffffffffu : 0x7fffffffu);
+                else b = (unsigned long long)__double_as_longlong(v4[q]) & (ps_exact ? ~0ull : 0x7fffffffffffffffull);
+                m = b > m ? b : m;
+            }
+        }
+    }
+    if (ps_acc) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(m, off); m = o > m ? o : m; }
+        if ((threadIdx.x & 63) == 0 && m) atomicMax(ps_acc + (size_t)parity * n_in + ch, m);
+        if (n == 0) ps_acc[(size_t)(parity ^ 1) * n_in + ch] = 0;
+    }
+}
+
+// after the spectrum has been written: a silent window's spectrum is zero (bfrun.c:1541-1553)
+template <typename T>
+__global__ __launch_bounds__(256) void
+big_ps_finish(const unsigned long long *__restrict__ ps_acc, int n_in, int parity, PowerSave ps,
+              c2<T> *__restrict__ ring, int R, int slot, int L) {
+    const int k = blockIdx.x * 256 + threadIdx.x, ch = blockIdx.y;
+    const unsigned long long m = ps_acc[(size_t)parity * n_in + ch];
+    bool silent;
+    if (ps.thr >= 1.0) silent = m == 0;
+    else {
+        double mag;
+        if constexpr (sizeof(T) == 4) mag = (double)__uint_as_float((unsigned int)m);
+        else mag = __longlong_as_double((long long)m);
+        silent = !(ps.scale[ch] * mag >= ps.thr);
+    }
+    if (k == 0) {
+        const int was = ps.flags[ch * R + slot], now = silent ? 1 : 0;
+        ps.flags[ch * R + slot] = now;
+        if (was != now) ps.live[ch] += was - now;
+    }
+    if (silent && k < L) ring[((size_t)ch * R + slot) * L + k] = mk<T>((T)0, (T)0);
 }
 
 // complex FFT of the packed window -> packed spectrum of the 2L real samples, times `scale`;

@@ -488,13 +488,14 @@ def test_prewarm_changes_cost_not_results(hip):
         b.prewarm()
 
 
+@pytest.mark.parametrize("L", [128, 16384])
 @pytest.mark.parametrize("rs", [4, 8])
 @pytest.mark.parametrize("mode", ["exact", "floor"])
-def test_powersave(hip, rs, mode):
+def test_powersave(hip, rs, mode, L):
     """`powersave: true` (exact-zero windows) changes no sample; `powersave: <dB>` makes windows
     below the noise floor silence (test_silent, bfrun.c:721-771).  Inputs go silent, come back,
     hover around the floor; one input never carries anything (its MAC entries are skipped)."""
-    L, N, I, O = 128, 4, 3, 2
+    N, I, O = 4, 3, 2
     coeffs = [(_ir(300 + k, L * N, I), 1.0, 0) for k in range(I * O)]
     filters = [dict(in_ch=[i], out_ch=[o], coeff=o * I + i, delayblocks=i % 2) for o in range(O) for i in range(I)]
     filters.append(dict(in_ch=[0, 1], in_scale=[0.5, 0.5], out_ch=[0], coeff=0))        # a private-ring filter
