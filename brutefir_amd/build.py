@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbfhip.so")
 SOURCES = ["bfhip.hip", "convolver_abi.hip", "nupc.hip"]
-DEPS = ["bfhip.hip", "convolver_abi.hip", "nupc.hip", "kernels.h", "fft_lds.h",
+DEPS = ["bfhip.hip", "convolver_abi.hip", "nupc.hip", "kernels.h", "fft_lds.h", "bigfft.h",
         os.path.join("..", "..", "include", "bfhip_nupc.h"),
         os.path.join("..", "..", "include", "bfhip.h"),
         os.path.join("..", "..", "include", "bfhip_convolver.h")]
