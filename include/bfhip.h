@@ -82,19 +82,20 @@ const char *bfhip_version(void);
 /* convolver_init(wisdom, length, realsize) (fftw_convolver.c:784-851) + the buffer set-up of
    filter_process() (bfrun.c:1227-1304, all zeroed as at :1388).  length = partition size L
    (power of two, 4..1048576: up to 8192 the transforms run in LDS, above as multi-kernel
-   sequences over global memory; the reference's stock `filter_length: 65536` is covered), n_blocks = N partitions per filter, realsize 4 or 8.
-   n_raw_in/out: size in bytes of one raw input / output buffer (dai_buffer_format->n_bytes).
+   sequences over global memory; the reference's stock `filter_length: 65536` is covered),
+   n_blocks = N partitions per filter, realsize 4 or 8.
    Device initialisation happens here, lazily on first use of the process: call it in the
    forked filter process, never in the parent. */
 bfhip_engine *bfhip_engine_create(int device, int length, int n_blocks, int realsize,
                                   int n_in, int n_out);
 void bfhip_engine_destroy(bfhip_engine *e);
 
-/* dai_buffer_format[io]->bf[channel] (dai.c:537-576); 1:1 virtual:physical channels */
+/* dai_buffer_format[io]->bf[channel] (dai.c:537-576) */
 int bfhip_engine_set_format(bfhip_engine *e, int io, int channel, const bfhip_format *bf);
 /* N:1 virtual -> physical channel mapping (`mapping:` in an input/output device section,
    bfconf->virt2phys / n_virtperphys).  Any mapping is legal (bench4_config: 0,1,0,1,0,1); the
-   members of a shared physical output are mixed in ascending virtual order.  After this call bfhip_engine_set_format addresses PHYSICAL channels.  For
+   members of a shared physical output are mixed in ascending virtual order.  After this call
+   bfhip_engine_set_format and bfhip_engine_enable_dither address PHYSICAL channels.  For
    channels that share a physical one, integer delay and mute happen inside the block like in
    filter_process() (bfrun.c:1509-1531, 1938-2003; delay.c) -- set them with the calls below at
    any time (what bfaccess->set_delay / toggle_mute write into icomm).  For 1:1 channels delay and
@@ -120,7 +121,9 @@ int bfhip_engine_set_safety_limit(bfhip_engine *e, double limit);
    10^(dB/20) < 1.0 = `powersave: <dB>`: windows below that level (full scale = 1.0) count as
    silence and are made zero, like the reference does.  Before finalize. */
 int bfhip_engine_set_powersave(bfhip_engine *e, double analog_powersave);
-/* outputs to dither + dither_init() parameters (dither.c:75-139, bfconf.c:3170-3230) */
+/* (physical) outputs to dither + dither_init() parameters (dither.c:75-139, bfconf.c:3170-3230);
+   outputs that share a physical channel or carry a sub-sample filter are dithered after their
+   mix / filter, like convolver_cbuf2raw on the mixbuf (bfrun.c:1992-1997) */
 int bfhip_engine_enable_dither(bfhip_engine *e, const int out_channels[], int n,
                                int sample_rate, int max_size);
 
