@@ -10,6 +10,14 @@ HBM) -> inverse FFTs -> 64 x L output samples.  Inputs are resident in HBM when 
 starts.  N > 1: the crossbar is sharded by input channel (brutefir_amd/sharding.py), one
 process per GPU, one RCCL reduce-scatter per block; total work is fixed ("strong" scaling).
 
+`python bench.py --gpus N` needs no outside launcher: the parent starts N fresh rank processes
+itself BEFORE it touches the GPU (the way the reference's host forks its own filter processes,
+bfrun.c:2312-2328), relays rank 0's line and exits with the ranks' return code.  It also runs
+unchanged under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (the
+ranks then come from the environment).  The transport of the mix-down is RCCL; anything else
+(no RCCL, fewer devices than ranks) is an error, never a silent fallback -- except when
+BFHIP_DIST_BACKEND=gloo is set explicitly (rehearsals on one GPU / CPU-side tests).
+
 Prints ONE JSON line (rank 0).
 """
 import argparse
@@ -113,7 +121,9 @@ def cpu_baseline(wl, seconds=10.0):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16, max(1, O // 2)))
+    # every core this process may run on (no cap): the reference's default is one filter process
+    # per core too (bfconf.c:2227-2318 spreads the filters over n_processes)
+    cores = max(1, cores)
     single = _cpu_worker((wl, 0, seconds / 2))
     agg, per = single[0], [single]
     if cores > 1:
@@ -134,8 +144,9 @@ def cpu_baseline(wl, seconds=10.0):
             per, agg = got, sum(g[0] for g in got)
         else:
             cores = 1                                 # report what was measured
-    ref_loop = reference_hot_loop(bo, L, rs, I, N)
+    ref_loop = reference_hot_loop(bo, L, rs, I, N, cores=cores)
     return {"value": agg, "unit": "samples/s", "cores": cores, "kind": "port",
+            "nproc": os.cpu_count(), "cpu_model": cpu_model(), "compiler_flags": "gcc -O2 (oracle), gcc -O2 -msse -msse2 (oracle/_ref)",
             "single_core_value": single[0],
             "reference_hot_loop": ref_loop,
             "sample": "per core: %d of %d outputs x %d inputs x %d partitions of %d taps, %d-%d steady-state "
@@ -143,18 +154,16 @@ def cpu_baseline(wl, seconds=10.0):
                       % (min(O, 2), O, I, N, L, min(p[1] for p in per), max(p[1] for p in per), seconds, cores)}
 
 
-def reference_hot_loop(bo, L, rs, I, N, seconds=3.0):
-    """The reference's OWN inner loop for this path -- convolve_add, the C version its dispatch
-    really selects and the SSE version it intends (SURVEY 0.4) -- compiled from the reference
-    sources into oracle/_ref and timed here on cbufs of the workload's size, cycling over a
-    working set larger than the last-level cache.  The full reference binary cannot be built
-    (FFTW3 absent); at this workload the loop is > 95 % of the reference's CPU time."""
+def _ref_loop_worker(L, rs, seconds, mib):
+    """time the reference's own convolve_add (C and SSE builds in oracle/_ref) on this core"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import bforacle as bo
     R = bo.ref()
     if R is None:
         return None
     R.ref_set_length(L, 0.0)
     dt = np.float32 if rs == 4 else np.float64
-    n_bufs = max(4, (512 << 20) // (2 * L * rs * 2))          # ~512 MiB of (b, c) pairs
+    n_bufs = max(4, (mib << 20) // (2 * L * rs * 2))          # (b, c) pairs, larger than the last-level cache
     rng = np.random.default_rng(1)
     b = rng.standard_normal((n_bufs, 2 * L)).astype(dt)
     c = rng.standard_normal((n_bufs, 2 * L)).astype(dt)
@@ -167,13 +176,135 @@ def reference_hot_loop(bo, L, rs, I, N, seconds=3.0):
             for k in range(n_bufs):
                 fn(rs, b[k].ctypes.data, c[k].ctypes.data, d.ctypes.data)
             calls += n_bufs
-        el = time.time() - t0
+        out[name] = (calls, time.time() - t0)
+    return out
+
+
+def reference_hot_loop(bo, L, rs, I, N, seconds=3.0, cores=1):
+    """The reference's OWN inner loop for this path -- convolve_add, the C version its dispatch
+    really selects and the SSE version it intends (SURVEY 0.4) -- compiled from the reference
+    sources into oracle/_ref and timed here on cbufs of the workload's size, cycling over a
+    working set larger than the last-level cache: on one core, and on all `cores` at once (one
+    process per core, the reference's n_processes model).  The full reference binary cannot be
+    built (FFTW3 absent); at this workload the loop is > 95 % of the reference's CPU time."""
+    import subprocess
+    if bo.ref() is None:
+        return None
+    one = _ref_loop_worker(L, rs, seconds, 512)
+    out = {}
+    for name, (calls, el) in one.items():
         per_call = el / calls
         # one output sample block (L samples) of one output costs I*N such calls
         out[name] = {"us_per_call": per_call * 1e6, "GB_per_s_3_streams": 3 * 2 * L * rs / per_call / 1e9,
                      "equivalent_samples_per_s": L / (I * N * per_call)}
-    out["note"] = "1 core, gcc -O2 -msse -msse2, %d-byte cbufs; equivalent rate = MAC only, FFTs excluded" % (2 * L * rs)
+    if cores > 1:
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--ref-worker", str(k),
+                                   "--ref-shape", "%d,%d" % (L, rs), "--cpu-seconds", str(seconds)],
+                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+                 for k in range(cores)]
+        got = []
+        for pr in procs:
+            try:
+                o, _ = pr.communicate(timeout=seconds + 120)
+                got.append(json.loads(o.strip().splitlines()[-1]))
+            except Exception:                         # noqa: BLE001
+                pr.kill()
+        if len(got) == cores and all(g is not None for g in got):
+            for name in one:
+                rate = sum(g[name][0] / g[name][1] for g in got)          # calls per second, all cores
+                out[name]["all_cores"] = {"cores": cores, "calls_per_s": rate,
+                                          "GB_per_s_3_streams": 3 * 2 * L * rs * rate / 1e9,
+                                          "equivalent_samples_per_s": L * rate / (I * N)}
+    out["note"] = ("gcc -O2 -msse -msse2, %d-byte cbufs; equivalent rate = MAC only, FFTs excluded; "
+                   "all_cores = %d processes at once, 128 MiB working set each" % (2 * L * rs, cores))
     return out
+
+
+def source_hash():
+    """sha256 over the device/host sources libbfhip.so is built from: what a committed profile
+    has to match to describe the binary that is being timed (there is no .git on the GPU box)"""
+    import hashlib
+    h = hashlib.sha256()
+    files = []
+    for d in ("brutefir_amd/csrc", "include"):
+        for name in sorted(os.listdir(os.path.join(ROOT, d))):
+            if name.endswith((".hip", ".h")):
+                files.append(os.path.join(d, name))
+    for rel in files:
+        h.update(rel.encode())
+        h.update(open(os.path.join(ROOT, rel), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N`, N > 1, started by hand: become the launcher.  This process
+    never initialises HIP (no torch.cuda call, no libbfhip call); it starts N fresh rank
+    processes with the torch.distributed environment, relays rank 0's JSON line and returns
+    the ranks' return code -- the reference's host likewise forks its own filter processes
+    (bfrun.c:2312-2328).  A rank that fails takes the others down (by PID)."""
+    import signal
+    import socket
+    import subprocess
+    import threading
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BFHIP_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # this pool's driver only does dmabuf IPC
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True,
+                                      start_new_session=True))
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout.readlines()), daemon=True)
+    reader.start()
+    deadline = time.time() + float(os.environ.get("BFHIP_BENCH_TIMEOUT", "1500"))
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is not None:
+                alive.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    sys.stderr.write("bench.py: rank %d exited with %d\n" % (r, code))
+        if (rc != 0 or time.time() > deadline) and alive:
+            if rc == 0:
+                rc = 124
+                sys.stderr.write("bench.py: ranks still running at the time limit\n")
+            for r in alive:                                  # exactly the processes started above
+                try:
+                    os.killpg(procs[r].pid, signal.SIGKILL)
+                except OSError:
+                    pass
+            for r in alive:
+                procs[r].wait()
+            alive = set()
+        if alive:
+            time.sleep(0.05)
+    reader.join(timeout=10)
+    lines = [ln for ln in out0 if ln.startswith("{")]
+    if rc == 0 and not lines:
+        sys.stderr.write("bench.py: rank 0 printed no result line\n")
+        rc = 1
+    if rc == 0:
+        sys.stdout.write(lines[-1])
+        sys.stdout.flush()
+    return rc
 
 
 def main():
@@ -188,49 +319,62 @@ def main():
                          "sync per block included) -- informative, never the headline value")
     ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help=argparse.SUPPRESS)
+    ap.add_argument("--ref-worker", type=int, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--ref-shape", default="8192,4", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.ref_worker is not None:
+        Lr, rsr = (int(v) for v in args.ref_shape.split(","))
+        print(json.dumps(_ref_loop_worker(Lr, rsr, args.cpu_seconds, 128)), flush=True)
+        return
     if args.cpu_worker is not None:
         # one core's share of the CPU baseline (a child of cpu_baseline()): oracle only, no GPU
         print(json.dumps(_cpu_worker((WORKLOADS[args.workload], args.cpu_worker, args.cpu_seconds))), flush=True)
         return
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        # no outside launcher: start the ranks ourselves, before anything here touches the GPU
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
     import torch
     import brutefir_amd as bf
     from brutefir_amd import sharding
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with that many ranks" % args.gpus)
     dist = None
     backend = os.environ.get("BFHIP_DIST_BACKEND", "nccl")
+    if backend not in ("nccl", "gloo"):
+        raise SystemExit("bench.py: BFHIP_DIST_BACKEND must be nccl (RCCL) or gloo")
     ndev = torch.cuda.device_count()
-    dev_index = local_rank % max(ndev, 1)
+    if ndev < 1:
+        raise SystemExit("bench.py: no GPU visible (there is no CPU path)")
+    if world > ndev and backend != "gloo":
+        # several ranks on one device would measure something else under the RCCL headline (and
+        # RCCL refuses duplicate devices); the gloo rehearsal has to be asked for explicitly
+        raise SystemExit("bench.py: --gpus %d but only %d device(s) visible; set BFHIP_DIST_BACKEND=gloo "
+                         "for a rehearsal with ranks sharing a device" % (world, ndev))
+    dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    fallback_note = ""
+    ranks_seen = [0]
     if world > 1:
         import torch.distributed as dist
-        try:
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
-            if backend == "nccl":                    # first collective = communicator set-up
-                probe = torch.ones(1, device=device)
-                dist.all_reduce(probe)
-                torch.cuda.synchronize()
-        except Exception as exc:                     # noqa: BLE001
-            if backend != "nccl":
-                raise
-            # never silently: the line says which transport carried the mix-down
-            sys.stderr.write("bench.py: RCCL not usable here (%s); mix-down over gloo host buffers instead\n" % exc)
-            try:
-                dist.destroy_process_group()
-            except Exception:                        # noqa: BLE001
-                pass
-            backend = "gloo"
-            fallback_note = " [RCCL failed to initialise: gloo host mix-down]"
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        # an RCCL failure is fatal (non-zero exit): never a different transport under this headline
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        got = [None] * world
+        dist.all_gather_object(got, {"rank": rank, "device": dev_index, "pid": os.getpid()})
+        ranks_seen = sorted(g["rank"] for g in got)
+        if ranks_seen != list(range(world)):
+            raise SystemExit("bench.py: ranks seen %s, expected 0..%d" % (ranks_seen, world - 1))
+        if backend == "nccl":                        # first device collective = communicator set-up
+            probe = torch.ones(1, device=device)
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            if int(probe.item()) != world:
+                raise SystemExit("bench.py: RCCL all-reduce returned %s, expected %d" % (probe.item(), world))
 
     wl = WORKLOADS[args.workload]
     I, O, L, N, rs, fmt = wl
@@ -286,6 +430,8 @@ def main():
         z_part = [torch.zeros(O, L, 2, dtype=tdt, device=device) for _ in range(depth)]
         z_loc = [torch.zeros(co, L, 2, dtype=tdt, device=device) for _ in range(depth)]
     pending = []          # (work handle, buffer index) of blocks whose mix-down is in flight
+    timed = [False]       # inside the timed region
+    wait_events = []      # (before, after) event pairs around the stream's wait for a collective
 
     host_in = [raw_in[i].cpu().numpy() for i in range(n_pool)] if args.host_io else None
     host_inflight = [0]
@@ -321,7 +467,16 @@ def main():
             # region; the pipeline is drained before the clock stops.
             if len(pending) == 2:
                 work, pb = pending.pop(0)
-                work.wait()                          # current stream waits for that collective
+                if timed[0] and k % 4 == 0:
+                    # how long the compute stream stalls for the collective (= what of it is NOT
+                    # hidden behind the previous block's kernels)
+                    ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ea.record()
+                    work.wait()                      # current stream waits for that collective
+                    eb.record()
+                    wait_events.append((ea, eb))
+                else:
+                    work.wait()
                 eng.outputs_inputs_dev(z_loc[pb], fo, co, raw_out, src)
             else:
                 eng.inputs_dev(src)
@@ -355,10 +510,10 @@ def main():
         step(k)
     drain()
     fence()
-    if world == 1:
-        # per-kernel HIP events on every 4th block of the timed region: the records themselves
-        # cost the stream ~20 us per block, which would otherwise be charged to `value`
-        eng.enable_timing(0 if os.environ.get("BFHIP_BENCH_NO_EVENTS") else (4 if args.steps >= 32 else 1))
+    # per-kernel HIP events on every 4th block of the timed region: the records themselves
+    # cost the stream ~20 us per block, which would otherwise be charged to `value`
+    eng.enable_timing(0 if os.environ.get("BFHIP_BENCH_NO_EVENTS") else (4 if args.steps >= 32 else 1))
+    timed[0] = True
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(args.warmup + k)
@@ -370,6 +525,27 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     status = eng.sync()
+    tm = eng.timing()
+    src_hash = source_hash()
+
+    def mac_roofline(tm_, alg_mac):
+        mac_s = tm_["mac_ms"] * 1e-3
+        ach = alg_mac / mac_s / 1e9 if mac_s > 0 else None
+        return {"bound": "hbm", "kernel": "mac_xbar_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS if ach else None,
+                "algorithmic_bytes_per_launch": alg_mac, "avg_launch_ms": tm_["mac_ms"],
+                "timed_launches": tm_["launches"]}
+
+    per_rank = None
+    if dist is not None:
+        exposed = [a.elapsed_time(b) for a, b in wait_events]
+        mine = {"rank": rank, "device": dev_index, "status_bits": status,
+                "inputs": [fi, fi + ci], "outputs": [fo, fo + co],
+                "mac_ms": tm["mac_ms"], "io_ms": tm["fft_in_ms"],
+                "exposed_collective_ms": sum(exposed) / len(exposed) if exposed else None,
+                "roofline": mac_roofline(tm, alg["mac"])}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     if rank == 0:
         ms = el * 1e3 / args.steps
@@ -386,34 +562,46 @@ def main():
                                                        I if args.workload in DIAGONAL else I * O),
                        "baseline_config": {"C": "configs[2]", "B": "configs[1]", "D": "configs[3] on one GPU",
                                            "E": "configs[4] (uniform partitions)"}.get(args.workload, "per-rank share of configs[2]"),
-                       "parallelism": ("input-sharded x%d + %s reduce-scatter%s%s"
-                                       % (world, "RCCL" if backend == "nccl" else "gloo (host)",
-                                          " (overlapped with the next block)" if pipelined else "", fallback_note))
+                       "parallelism": ("input-sharded x%d + %s reduce-scatter%s"
+                                       % (world, "RCCL" if backend == "nccl" else "gloo (host, rehearsal)",
+                                          " (overlapped with the next block)" if pipelined else ""))
                                       if world > 1
                                       else "single GPU",
-                       "status_bits": status},
+                       "status_bits": status if per_rank is None else max(p["status_bits"] for p in per_rank)},
             "hbm_gbs_algorithmic": alg["block"] / (ms * 1e-3) / 1e9 if world == 1 else None,
         }
         if args.host_io:
             out["config"]["io"] = "host buffers through bfhip_engine_rt_submit/rt_wait, two blocks in flight (PCIe-inclusive)"
+        out["source_hash"] = src_hash
         if world == 1:
-            tm = eng.timing()
-            traffic = None
+            traffic, traffic_stale, traffic_src = None, None, None
             tp = os.path.join(ROOT, "profiles", "traffic_config%s.json" % args.workload)
             if os.path.exists(tp):
                 # HBM bytes per MAC launch from the committed rocprofv3 PMC passes of this very
-                # workload (counters cannot be read from inside this process)
-                traffic = json.load(open(tp))["traffic_bytes_per_launch"]
-            mac_s = tm["mac_ms"] * 1e-3
-            ach = alg["mac"] / mac_s / 1e9 if mac_s > 0 else None
-            out["roofline"] = {"bound": "hbm", "kernel": "mac_xbar_kernel", "achieved": ach,
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": traffic,
-                               "algorithmic_bytes_per_launch": alg["mac"],
-                               "avg_launch_ms": tm["mac_ms"], "launches": args.steps, "timed_launches": tm["launches"],
-                               "fft_in_ms": tm["fft_in_ms"], "ifft_out_ms": tm["ifft_out_ms"]}
+                # workload (counters cannot be read from inside this process).  The file names
+                # the sources it was measured on; a different binary is flagged, not trusted.
+                tj = json.load(open(tp))
+                traffic = tj["traffic_bytes_per_launch"]
+                traffic_src = tj.get("source_hash")
+                traffic_stale = traffic_src != src_hash
+            rf = mac_roofline(tm, alg["mac"])
+            rf.update({"traffic": traffic, "traffic_stale": traffic_stale, "traffic_source_hash": traffic_src,
+                       "launches": args.steps, "fft_in_ms": tm["fft_in_ms"], "ifft_out_ms": tm["ifft_out_ms"]})
+            out["roofline"] = rf
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(wl)
+        else:
+            # the dominant kernel on the slowest rank prices the job; every rank's own figure beside it
+            slow = max(per_rank, key=lambda p_: p_["mac_ms"])
+            rf = dict(slow["roofline"])
+            rf.update({"traffic": None, "rank": slow["rank"],
+                       "note": "per-rank MAC launch (1/%d of the inputs, all outputs); slowest rank shown" % world})
+            out["roofline"] = rf
+            out["ranks_seen"] = ranks_seen
+            out["per_rank"] = per_rank
+            ex = [p_["exposed_collective_ms"] for p_ in per_rank if p_["exposed_collective_ms"] is not None]
+            out["exposed_collective_ms"] = max(ex) if ex else None
+            out["backend"] = "rccl" if backend == "nccl" else "gloo"
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

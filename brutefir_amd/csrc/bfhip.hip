@@ -317,6 +317,9 @@ struct bfhip_engine {
     int ev_used = 0;
     int timing_stride = 1;         // time every n-th block (the event records cost ~3 us each)
     bool timed_now = false;
+    int timed_mask = 0;            // which of the three kernel pairs of the block in progress were recorded
+    unsigned long long timed_for = ~0ull;   // blocks_done the decision above was taken for
+    std::vector<unsigned char> ev_mask;     // [MAX_TIMED] timed_mask of every timed block
 
     size_t csize() const { return (size_t)2 * rs; }     // bytes per complex
 };
@@ -1069,7 +1072,17 @@ int check_format(const bfhip_format *f) {
 int record(bfhip_engine *e, int idx) {
     if (!e->timed_now) return BFHIP_OK;
     HIPCHK(hipEventRecord(e->ev[(size_t)e->ev_used * 6 + idx], e->ls));
+    if (idx & 1) e->timed_mask |= 1 << (idx >> 1);
     return BFHIP_OK;
+}
+
+// is the block in progress one of the timed ones?  Decided once per block, by whichever entry
+// point touches it first (block_dev, or the phase calls of a multi-GPU host).
+void timing_begin(bfhip_engine *e) {
+    if (e->timed_for == e->blocks_done) return;
+    e->timed_for = e->blocks_done;
+    e->timed_mask = 0;
+    e->timed_now = e->timing && e->ev_used < MAX_TIMED && e->blocks_done % (unsigned long long)e->timing_stride == 0;
 }
 
 int ensure_ready(bfhip_engine *e) {
@@ -1278,6 +1291,10 @@ int do_outputs(bfhip_engine *e, const void *Zp, size_t chunk_stride, int n_chunk
 }
 
 void advance(bfhip_engine *e) {
+    if (e->timed_now) {
+        if (e->timed_mask) { e->ev_mask[e->ev_used] = (unsigned char)e->timed_mask; e->ev_used++; }
+        e->timed_now = false;
+    }
     e->blockcounter++;                                   // bfrun.c:2034 (unsigned wrap)
     e->blocks_done++;
     for (auto &f : e->filters) f.prevcoeff = f.coeff;    // bfrun.c:1838
@@ -2169,16 +2186,26 @@ int bfhip_engine_inputs_dev(bfhip_engine *e, const void *rawin_dev) {
     int r = ensure_ready(e);
     if (r != BFHIP_OK) return r;
     e->ls = e->stream;
-    return do_inputs(e, rawin_dev);
+    timing_begin(e);
+    if ((r = record(e, 0)) != BFHIP_OK) return r;
+    if ((r = do_inputs(e, rawin_dev)) != BFHIP_OK) return r;
+    return record(e, 1);
 }
 
 int bfhip_engine_mac_dev(bfhip_engine *e, void *z_dev) {
     int r = ensure_ready(e);
     if (r != BFHIP_OK) return r;
+    e->ls = e->stream;
+    timing_begin(e);
     if ((r = do_levels(e)) != BFHIP_OK) return r;
-    if (e->n_chunks == 1 && e->n_out_padded == e->n_ch[1]) return do_mac(e, z_dev);
+    if ((r = record(e, 2)) != BFHIP_OK) return r;
+    if (e->n_chunks == 1 && e->n_out_padded == e->n_ch[1]) {
+        if ((r = do_mac(e, z_dev)) != BFHIP_OK) return r;
+        return record(e, 3);
+    }
     r = do_mac(e, e->d_Zp);
     if (r != BFHIP_OK) return r;
+    if ((r = record(e, 3)) != BFHIP_OK) return r;
     hipError_t err = hipSuccess;
     if (e->rs == 4) launch_sum<float>(e, e->d_Zp, z_dev, &err); else launch_sum<double>(e, e->d_Zp, z_dev, &err);
     if (err != hipSuccess) return fail(BFHIP_EHIP, "sum_partials launch: %s", hipGetErrorString(err));
@@ -2189,7 +2216,11 @@ int bfhip_engine_outputs_dev(bfhip_engine *e, const void *z_dev, int first, int 
     int r = ensure_ready(e);
     if (r != BFHIP_OK) return r;
     if (first < 0 || count < 0 || first + count > e->n_ch[1]) return fail(BFHIP_EINVAL, "outputs: channel range");
-    return do_outputs(e, z_dev, 0, 1, first, count, rawout_dev);
+    e->ls = e->stream;
+    timing_begin(e);
+    if ((r = record(e, 4)) != BFHIP_OK) return r;
+    if ((r = do_outputs(e, z_dev, 0, 1, first, count, rawout_dev)) != BFHIP_OK) return r;
+    return record(e, 5);
 }
 
 int bfhip_engine_outputs_inputs_dev(bfhip_engine *e, const void *z_dev, int first, int count,
@@ -2203,11 +2234,13 @@ int bfhip_engine_outputs_inputs_dev(bfhip_engine *e, const void *z_dev, int firs
         return bfhip_engine_inputs_dev(e, rawin_dev);
     }
     e->ls = e->stream;
+    timing_begin(e);
+    if ((r = record(e, 0)) != BFHIP_OK) return r;      // the fused launch is timed in the input slot
     hipError_t err = hipSuccess;
     const int slot = (int)(e->blockcounter % (unsigned int)e->R);
     DISPATCH(launch_io, e, z_dev, first, count, (uint8_t *)rawout_dev, (const uint8_t *)rawin_dev, slot, &err);
     if (err != hipSuccess) return fail(BFHIP_EHIP, "io launch: %s", hipGetErrorString(err));
-    return BFHIP_OK;
+    return record(e, 1);
 }
 
 int bfhip_engine_advance(bfhip_engine *e) {
@@ -2222,7 +2255,7 @@ int bfhip_engine_block_dev(bfhip_engine *e, const void *rawin_dev, void *rawout_
     const bool pipe = e->pipelined;
     const int buf = (int)(e->blocks_done & 1);
     void *Zp = (pipe && buf) ? e->d_Zp2 : e->d_Zp;
-    e->timed_now = e->timing && e->ev_used < MAX_TIMED && e->blocks_done % (unsigned long long)e->timing_stride == 0;
+    timing_begin(e);
 
     // K1 on the input stream.  It overwrites the ring slot of block t-R, last read by the MAC
     // of block t-2 (the MAC of t-1 reaches back only N = R-1 blocks).
@@ -2254,8 +2287,6 @@ int bfhip_engine_block_dev(bfhip_engine *e, const void *rawin_dev, void *rawout_
     if ((r = record(e, 5)) != BFHIP_OK) return r;
     if (pipe) HIPCHK(hipEventRecord(e->ev_out[buf], e->s_out));
     e->ls = e->stream;
-    if (e->timed_now) e->ev_used++;
-    e->timed_now = false;
     advance(e);
     return BFHIP_OK;
 }
@@ -2504,11 +2535,14 @@ int bfhip_engine_enable_timing(bfhip_engine *e, int on) {
     if (on && e->ev.empty()) {
         e->ev.resize((size_t)MAX_TIMED * 6);
         for (auto &x : e->ev) HIPCHK(hipEventCreate(&x));
+        e->ev_mask.assign(MAX_TIMED, 0);
     }
     { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
     e->timing = on != 0;
     e->timing_stride = on > 1 ? on : 1;
     e->ev_used = 0;
+    e->timed_for = ~0ull;
+    e->timed_now = false;
     return BFHIP_OK;
 }
 
@@ -2516,15 +2550,19 @@ int bfhip_engine_get_timing(bfhip_engine *e, double ms[4]) {
     if (!e || !ms) return fail(BFHIP_EINVAL, "get_timing: bad argument");
     HIPCHK(hipSetDevice(e->device));
     { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
-    ms[0] = ms[1] = ms[2] = 0; ms[3] = e->ev_used;
+    ms[0] = ms[1] = ms[2] = ms[3] = 0;
+    int cnt[3] = {0, 0, 0};
     for (int i = 0; i < e->ev_used; i++) {
         for (int k = 0; k < 3; k++) {
+            if (!(e->ev_mask[i] & (1 << k))) continue;      // phase not launched through a timed entry point
             float t = 0;
             HIPCHK(hipEventElapsedTime(&t, e->ev[(size_t)i * 6 + 2 * k], e->ev[(size_t)i * 6 + 2 * k + 1]));
             ms[k] += t;
+            cnt[k]++;
         }
     }
-    if (e->ev_used > 0) for (int k = 0; k < 3; k++) ms[k] /= e->ev_used;
+    for (int k = 0; k < 3; k++) if (cnt[k] > 0) ms[k] /= cnt[k];
+    ms[3] = cnt[1];
     e->ev_used = 0;
     return BFHIP_OK;
 }

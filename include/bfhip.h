@@ -267,8 +267,10 @@ int bfhip_engine_ring_depth(const bfhip_engine *e);
 
 /* HIP-event timing of the three kernels of a block on the engine's stream.  ms[0..2] =
    mean duration of the input-FFT, MAC and output-IFFT launches since the last reset,
-   ms[3] = launches averaged.  Reading synchronises the stream.  on = n > 1 times every n-th
-   block only (six event records per timed block cost the stream ~20 us). */
+   ms[3] = MAC launches averaged.  Reading synchronises the stream.  on = n > 1 times every n-th
+   block only (six event records per timed block cost the stream ~20 us).  The phase calls
+   (inputs_dev / mac_dev / outputs_dev) are timed the same way; the fused
+   bfhip_engine_outputs_inputs_dev launch is reported in the input slot ms[0]. */
 int bfhip_engine_enable_timing(bfhip_engine *e, int on);
 int bfhip_engine_get_timing(bfhip_engine *e, double ms[4]);
 /* algorithmic bytes of one block per SURVEY 8(d): bytes[0] total, [1] MAC kernel only

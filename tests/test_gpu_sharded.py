@@ -137,18 +137,43 @@ def test_phase_api_and_fused_io_launch_equal_the_block_call(hip):
 
 
 def test_bench_two_rank_pipeline_on_one_gpu():
-    """bench.py's N > 1 code path end to end (torch.distributed.run, sharding, the two-deep
-    block pipeline with the fused launch), two ranks sharing cuda:0 over gloo, small workload;
-    the JSON line must come out and report no status bits"""
+    """bench.py's N > 1 code path end to end, started the way a user starts it: plain
+    `python bench.py --gpus 2`, no outside launcher.  The parent forks its own two ranks (like
+    the reference's host forks its filter processes, bfrun.c:2312-2328); they share cuda:0 over
+    gloo (asked for explicitly -- without BFHIP_DIST_BACKEND=gloo two ranks on one device are an
+    error, next test).  The JSON line must come out, name both ranks and report no status bits."""
     import json
     import subprocess
     env = dict(os.environ, BFHIP_DIST_BACKEND="gloo")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "10",
-                        "--workload", "B"], capture_output=True, text=True, timeout=280, env=env)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8",
+                        "--warmup", "10", "--workload", "B"], capture_output=True, text=True, timeout=280, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
-    d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 0
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 8 and d["value"] > 0
     assert d["config"]["status_bits"] == 0 and d["scaling"] == "strong"
+    assert d["ranks_seen"] == [0, 1] and d["backend"] == "gloo"
+    assert [p["rank"] for p in d["per_rank"]] == [0, 1]
+    for p in d["per_rank"]:
+        assert p["mac_ms"] > 0 and p["roofline"]["achieved"] > 0
+        assert p["roofline"]["algorithmic_bytes_per_launch"] > 0
+    assert d["roofline"]["frac"] > 0 and "exposed_collective_ms" in d
+
+
+def test_bench_refuses_two_ranks_on_one_device_under_the_rccl_headline():
+    """no silent change of transport or topology: `--gpus 2` on a one-GPU box without the
+    explicit gloo switch exits non-zero and prints no result line"""
+    import subprocess
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with a single GPU")
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BFHIP_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                        "--warmup", "2", "--workload", "B"], capture_output=True, text=True, timeout=280, env=env)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "BFHIP_DIST_BACKEND=gloo" in r.stderr

@@ -103,3 +103,27 @@ def test_load_balance_follows_the_reference_rules():
     # two islands: {0 -> 2} share nothing with {1, 3 mixing into output 5}
     isl = [dict(out_ch=[0]), dict(out_ch=[5]), dict(in_f=[0], out_ch=[1]), dict(out_ch=[5, 6])]
     assert load_balance_filters(isl, 2) == ([0, 1, 0, 1], 2)
+
+
+def test_bench_self_launch_relays_rank_failure_without_a_gpu():
+    """`python bench.py --gpus 2` is its own launcher (bench.py:self_launch): the parent starts
+    the ranks before it touches any GPU and hands back their return code.  Without a GPU (this
+    container) every rank exits with "no GPU visible": the parent must come back non-zero,
+    promptly, with no result line -- never hang, never fall back to a CPU path."""
+    import subprocess
+    import time
+    try:
+        import torch
+        if torch.cuda.device_count() > 0:
+            pytest.skip("a GPU is visible: covered by tests/test_gpu_sharded.py")
+    except ImportError:
+        pass
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                        "--warmup", "1", "--workload", "B"], capture_output=True, text=True, timeout=170, env=env)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "no GPU visible" in r.stderr
+    assert time.time() - t0 < 150

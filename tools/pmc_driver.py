@@ -15,24 +15,27 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import brutefir_amd as bf  # noqa: E402
 
-WL = {"C": (64, 64, 8192, 32), "B": (8, 8, 8192, 8), "S": (16, 16, 8192, 32)}
+WL = {"C": (64, 64, 8192, 32, 4), "B": (8, 8, 8192, 8, 4), "S": (16, 16, 8192, 32, 4),
+      "F": (32, 32, 8192, 32, 8)}       # F: the float64 crossbar of bench.py --workload F
 
 
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "C"
     steady = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-    I, O, L, N = WL[name]
-    e = bf.Engine(L, N, 4, I, O)
-    e.set_interleaved(bf.IN, "S24_4LE")
-    e.set_interleaved(bf.OUT, "S24_4LE")
+    I, O, L, N, rs = WL[name]
+    fmt = "S24_4LE" if rs == 4 else "FLOAT64_LE"
+    e = bf.Engine(L, N, rs, I, O)
+    e.set_interleaved(bf.IN, fmt)
+    e.set_interleaved(bf.OUT, fmt)
     rng = np.random.default_rng(5)
     h = rng.standard_normal(L * N) * np.exp(-np.arange(L * N) / (L * N / 6.0))
-    h = (h / (np.abs(h).sum() * I)).astype(np.float32)
+    h = (h / (np.abs(h).sum() * I)).astype(np.float32 if rs == 4 else np.float64)
     for o in range(O):
         for i in range(I):
             e.add_filter(in_ch=[i], out_ch=[o], coeff=e.add_coeff(h))
     e.finalize()
-    raw = (rng.standard_normal((L, I)) * 0.1 * 8388608).astype(np.int32)
+    raw = ((rng.standard_normal((L, I)) * 0.1 * 8388608).astype(np.int32) if rs == 4
+           else rng.standard_normal((L, I)) * 0.1)
     for _ in range(N + steady):
         st, _out = e.block(raw)
         assert st == 0
