@@ -95,6 +95,12 @@ def lib():
     L.bfhip_engine_update_coeff_block.argtypes = [vp, ci, ci, vp]
     L.bfhip_engine_add_coeff_processed.argtypes = [vp, vp, ci]
     L.bfhip_engine_read_coeff_processed.argtypes = [vp, ci, vp]
+    L.bfhip_engine_add_coeff_processed_blocks.argtypes = [vp, C.POINTER(vp), ci, ci]
+    L.bfhip_engine_refresh_coeff_processed.argtypes = [vp, ci, ci, vp]
+    L.bfhip_engine_poll_coeff_changes.argtypes = [vp]
+    L.bfhip_coeff_mark_dirty.argtypes = [vp]
+    L.bfhip_coeff_mark_dirty.restype = None
+    L.bfhip_coeff_dirty_sequence.restype = C.c_ulonglong
     L.bfhip_engine_add_filter.argtypes = [vp, ci, ip, dp, ci, ip, dp, ci, ip, dp, ci, ci, ci]
     L.bfhip_engine_finalize.argtypes = [vp]
     L.bfhip_engine_set_coeff.argtypes = [vp, ci, ci]
@@ -261,6 +267,18 @@ class Engine:
         """cbufs: [n_blocks, 2L] reals in the reference's internal layout"""
         cbufs = np.ascontiguousarray(cbufs, self.dt)
         return _check(lib().bfhip_engine_add_coeff_processed(self.h, _ptr(cbufs), cbufs.shape[0]))
+
+    def add_coeff_processed_blocks(self, addresses, watch=False):
+        """addresses: host address of each block's cbuf (separate allocations, the reference's
+        bfconf->coeffs_data[c][i]); watch: re-upload blocks another process marks dirty"""
+        arr = (C.c_void_p * len(addresses))(*addresses)
+        return _check(lib().bfhip_engine_add_coeff_processed_blocks(self.h, arr, len(addresses), int(watch)))
+
+    def refresh_coeff_processed(self, coeff, block, cbuf=None):
+        _check(lib().bfhip_engine_refresh_coeff_processed(self.h, coeff, block, _ptr(cbuf)))
+
+    def poll_coeff_changes(self):
+        return _check(lib().bfhip_engine_poll_coeff_changes(self.h))
 
     def read_coeff_processed(self, coeff, n_blocks):
         out = np.empty((n_blocks, 2 * self.L), self.dt)

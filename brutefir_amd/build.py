@@ -18,17 +18,14 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libbfhip.so")
 INC = os.path.join(HERE, "..", "include")
-HEADERS = ["kernels.h", "fft_lds.h", "bigfft.h", "host_fft.h",
-           os.path.join("..", "..", "include", "bfhip_nupc.h"),
-           os.path.join("..", "..", "include", "bfhip.h"),
-           os.path.join("..", "..", "include", "bfhip_convolver.h")]
-# translation unit -> headers it includes (besides the public ones)
+PUBLIC = [os.path.join("..", "..", "include", h) for h in ("bfhip.h", "bfhip_convolver.h", "bfhip_nupc.h")]
+DEVICE = ["kernels.h", "fft_lds.h", "bigfft.h"] + PUBLIC
+# translation unit -> what it includes
 UNITS = {
-    "bfhip.hip": HEADERS,
-    "convolver_abi.hip": HEADERS,
-    "nupc.hip": HEADERS,
-    "host_ops.cpp": ["host_fft.h", os.path.join("..", "..", "include", "bfhip_convolver.h"),
-                     os.path.join("..", "..", "include", "bfhip.h")],
+    "bfhip.hip": DEVICE + ["conv_shared.h"],
+    "convolver_abi.hip": DEVICE + ["conv_shared.h"],
+    "nupc.hip": DEVICE,
+    "host_ops.cpp": ["host_fft.h", "conv_shared.h"] + PUBLIC,
 }
 
 

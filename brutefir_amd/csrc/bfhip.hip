@@ -25,6 +25,7 @@
 #include <tuple>
 
 #include "../../include/bfhip.h"
+#include "conv_shared.h"
 #include "kernels.h"
 #include "bigfft.h"
 
@@ -61,6 +62,11 @@ int ilog2(int v) {
 struct Coeff {
     int n_blocks = 0;
     void *d_H = nullptr;     // [n_blocks][L] packed spectra
+    // a set the host keeps in (shared) memory in the reference's cbuf layout and that another
+    // process may rewrite at run time (bflogic_eq through bfaccess->convolver_coeffs2cbuf):
+    // where each block lives on the host, and the change-notice generation last uploaded
+    std::vector<const void *> watch_src;
+    std::vector<uint64_t> watch_gen;
 };
 
 struct Filter {
@@ -176,6 +182,8 @@ struct bfhip_engine {
     unsigned long long *d_ps_acc = nullptr;    // partition lengths above 8192: [2][n_in] running maxima
     double *d_ps_scale = nullptr;
     std::vector<Coeff> coeffs;
+    bool any_watched = false;
+    unsigned long long watch_seq = 0;       // bfhip_coeff_dirty_sequence() at the last poll
     std::vector<Filter> filters;
     bool finalized = false, plan_dirty = true;
     unsigned int blockcounter = 0;
@@ -1085,9 +1093,17 @@ void timing_begin(bfhip_engine *e) {
     e->timed_now = e->timing && e->ev_used < MAX_TIMED && e->blocks_done % (unsigned long long)e->timing_stride == 0;
 }
 
+int poll_coeff_changes(bfhip_engine *e);
+
 int ensure_ready(bfhip_engine *e) {
     if (!e->finalized) return fail(BFHIP_ESTATE, "engine not finalized");
     HIPCHK(hipSetDevice(e->device));
+    if (e->any_watched) {
+        // one load of a shared counter per block; a partition another process rewrote since the
+        // last block is re-uploaded now, before this block's plan / coefficient switch is applied
+        const int r = poll_coeff_changes(e);
+        if (r < 0) return r;
+    }
     if (e->plan_dirty) {
         e->rt.valid[0] = e->rt.valid[1] = false;     // captured launches point into the old plan
         e->rt.primed = false;
@@ -1299,6 +1315,28 @@ void advance(bfhip_engine *e) {
     e->blocks_done++;
     for (auto &f : e->filters) f.prevcoeff = f.coeff;    // bfrun.c:1838
     if (e->any_fading) e->plan_dirty = true;             // the fade lasts exactly one block
+}
+
+// Re-upload the watched partitions whose change notice moved (bfhip_coeff_mark_dirty, written by
+// convolver_runtime_coeffs2cbuf in whichever process renders new coefficients).  Returns the
+// number of partitions refreshed.
+int poll_coeff_changes(bfhip_engine *e) {
+    const unsigned long long seq = bfhip_coeff_dirty_sequence();
+    if (seq == e->watch_seq) return 0;
+    e->watch_seq = seq;
+    int n = 0;
+    for (size_t ci = 0; ci < e->coeffs.size(); ci++) {
+        Coeff &c = e->coeffs[ci];
+        for (size_t b = 0; b < c.watch_src.size(); b++) {
+            const uint64_t gen = bfhip_dirty_generation(c.watch_src[b]);
+            if (gen == c.watch_gen[b]) continue;
+            c.watch_gen[b] = gen;
+            const int r = bfhip_engine_refresh_coeff_processed(e, (int)ci, (int)b, c.watch_src[b]);
+            if (r != BFHIP_OK) return r;
+            n++;
+        }
+    }
+    return n;
 }
 
 // ---------------------------------------------------------------- real-time mode
@@ -1799,6 +1837,74 @@ int bfhip_engine_add_coeff(bfhip_engine *e, const void *taps, int n_taps, double
 
 int bfhip_engine_add_coeff_dev(bfhip_engine *e, const void *taps_dev, int n_taps, double scale, int n_blocks) {
     return add_coeff_common(e, taps_dev, true, n_taps, scale, n_blocks);
+}
+
+// one cbuf (2L reals, the reference's "4 re / 4 im" layout) -> packed partition `block` of set c
+static int upload_processed_block(bfhip_engine *e, Coeff &c, int block, const void *cbuf) {
+    const size_t n = (size_t)2 * e->L;
+    for (size_t i = 0; i < n; i++) {           // convolver_verify_cbuf (fftw_convolver.c:598-622)
+        const double v = e->rs == 4 ? (double)((const float *)cbuf)[i] : ((const double *)cbuf)[i];
+        if (!std::isfinite(v)) return fail(BFHIP_EINVAL, "NaN or Inf value among coefficients.");
+    }
+    const size_t bytes = n * e->rs;
+    if (bytes > e->taps_cap) {
+        if (e->d_taps) { { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; } (void)hipFree(e->d_taps); e->d_taps = nullptr; }
+        HIPCHK(hipMalloc(&e->d_taps, bytes));
+        e->taps_cap = bytes;
+    }
+    { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }      // d_taps is reused; nothing may still read H
+    HIPCHK(hipMemcpy(e->d_taps, cbuf, bytes, hipMemcpyHostToDevice));
+    void *H = (unsigned char *)c.d_H + (size_t)block * e->L * e->csize();
+    const dim3 grid((e->L + 255) / 256, 1);
+    if (e->rs == 4)
+        hipLaunchKernelGGL(reorder_kernel<float>, grid, dim3(256), 0, e->stream, (const float *)e->d_taps, (c2<float> *)H, e->L, 1, (float *)nullptr);
+    else
+        hipLaunchKernelGGL(reorder_kernel<double>, grid, dim3(256), 0, e->stream, (const double *)e->d_taps, (c2<double> *)H, e->L, 1, (double *)nullptr);
+    HIPCHK(hipGetLastError());
+    { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
+    return BFHIP_OK;
+}
+
+int bfhip_engine_add_coeff_processed_blocks(bfhip_engine *e, void *const cbufs[], int n_blocks, int watch) {
+    if (!e || !cbufs || n_blocks < 1) return fail(BFHIP_EINVAL, "add_coeff_processed_blocks: bad argument");
+    if (n_blocks > e->N) return fail(BFHIP_EINVAL, "coefficient set has %d blocks, engine has %d", n_blocks, e->N);
+    for (int b = 0; b < n_blocks; b++) if (!cbufs[b]) return fail(BFHIP_EINVAL, "add_coeff_processed_blocks: block %d is NULL", b);
+    HIPCHK(hipSetDevice(e->device));
+    Coeff c;
+    c.n_blocks = n_blocks;
+    if (hipMalloc(&c.d_H, (size_t)n_blocks * e->L * e->csize()) != hipSuccess)
+        return fail(BFHIP_ENOMEM, "out of device memory for coefficient set");
+    for (int b = 0; b < n_blocks; b++) {
+        // generation first, data second: a notice that arrives in between is seen by the next poll
+        const uint64_t gen = watch ? bfhip_dirty_generation(cbufs[b]) : 0;
+        const int r = upload_processed_block(e, c, b, cbufs[b]);
+        if (r != BFHIP_OK) { (void)hipFree(c.d_H); return r; }
+        if (watch) { c.watch_src.push_back(cbufs[b]); c.watch_gen.push_back(gen); }
+    }
+    if (watch) {
+        e->any_watched = true;
+        // (watch_seq stays where it is: a notice older than this call costs one extra scan)
+    }
+    e->coeffs.push_back(c);
+    return (int)e->coeffs.size() - 1;
+}
+
+int bfhip_engine_refresh_coeff_processed(bfhip_engine *e, int coeff, int block, const void *cbuf) {
+    if (!e || coeff < 0 || coeff >= (int)e->coeffs.size() || block < 0 || block >= e->coeffs[coeff].n_blocks)
+        return fail(BFHIP_EINVAL, "refresh_coeff_processed: bad argument");
+    Coeff &c = e->coeffs[coeff];
+    if (cbuf == nullptr) {
+        if (c.watch_src.empty()) return fail(BFHIP_EINVAL, "refresh_coeff_processed: no host buffer known for this set");
+        cbuf = c.watch_src[block];
+    }
+    HIPCHK(hipSetDevice(e->device));
+    return upload_processed_block(e, c, block, cbuf);
+}
+
+int bfhip_engine_poll_coeff_changes(bfhip_engine *e) {
+    if (!e) return fail(BFHIP_EINVAL, "null engine");
+    HIPCHK(hipSetDevice(e->device));
+    return poll_coeff_changes(e);
 }
 
 int bfhip_engine_add_coeff_processed(bfhip_engine *e, const void *cbufs, int n_blocks) {

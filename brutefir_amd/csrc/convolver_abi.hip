@@ -1,5 +1,7 @@
-// convolver_abi.hip -- the 22 link-time symbols of the reference's convolver.h
-// (include/bfhip_convolver.h), host-memory semantics, executed on the device.
+// convolver_abi.hip -- the per-block symbols of the reference's convolver.h
+// (include/bfhip_convolver.h), host-memory semantics, executed on the device.  The symbols
+// that run before the fork or in module processes (init, coeffs2cbuf, runtime_coeffs2cbuf,
+// verify, debug dump, fftplan, td_new) are pure host code in host_ops.cpp.
 //
 // Layouts here are the REFERENCE's (halfcomplex, "4 re / 4 im" reordered), not the engine's
 // packed spectra: these entry points exchange buffers with unmodified host code
@@ -19,6 +21,7 @@
 #include <vector>
 
 #include "../../include/bfhip_convolver.h"
+#include "conv_shared.h"
 #include "kernels.h"
 #include "bigfft.h"
 
@@ -99,12 +102,6 @@ __global__ void k_conv_ordered(T *b, const T *c, int size) {
     const T a = b[n], bi = b[size - n];
     b[n] = nsub(nmul(a, c[n]), nmul(bi, c[size - n]));
     b[size - n] = nadd(nmul(a, c[size - n]), nmul(bi, c[n]));
-}
-
-template <typename T>
-__global__ void k_scale_all(T *b, T s, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) b[i] = nmul(b[i], s);
 }
 
 // FFTW R2HC of 2L reals (in may equal out)
@@ -219,20 +216,6 @@ __global__ void k_raw2real(const uint8_t *raw, DevFormat f, T *out, int n_sample
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= n_samples) return;
     out[n] = load_raw<T>(raw + f.byte_offset + (size_t)n * f.sample_spacing * f.bytes, f);
-}
-
-// taps -> [L zeros | taps * scale] with finite check (fftw_convolver.c:535-547)
-template <typename T>
-__global__ void k_pad_scale(const T *taps, int len, T scale, T *out, int L, int *bad) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= L) return;
-    out[n] = (T)0;
-    T v = (T)0;
-    if (n < len) {
-        v = nmul(taps[n], scale);
-        if (!isfinite(v)) atomicOr(bad, 1);
-    }
-    out[L + n] = v;
 }
 
 // real2raw without dither (real2raw.h:61-250 + dither_funs.h:71-114), one workgroup
@@ -361,9 +344,6 @@ struct State {
     std::vector<size_t> cap;
     int *d_flag = nullptr;
     DevOverflow *d_over = nullptr;
-    int last_fatal = 0;
-    void (*handler)(int, const char *) = nullptr;
-    std::vector<void *> coeff_allocs;
 } G;
 
 void fatal(int code, const char *fmt, ...) {
@@ -372,10 +352,7 @@ void fatal(int code, const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(msg, sizeof(msg), fmt, ap);
     va_end(ap);
-    G.last_fatal = code;
-    if (G.handler) { G.handler(code, msg); return; }
-    fprintf(stderr, "%s\n", msg);
-    exit(1);                                  /* BF_EXIT_OTHER, what bf_exit() passes on */
+    bfhip_conv_fatal(code, msg);              /* handler, or print + exit(BF_EXIT_OTHER) */
 }
 
 #define DCHK(expr)                                                                     \
@@ -385,19 +362,27 @@ void fatal(int code, const char *fmt, ...) {
     } while (0)
 
 bool ensure_device() {
-    if (!G.inited) { fatal(101, "convolver_init() has not been called."); return false; }
+    if (!bfhip_conv_g.inited) { fatal(101, "convolver_init() has not been called."); return false; }
+    // convolver_init() may have been called again (tests do): the sizes live in host_ops.cpp
+    G.L = bfhip_conv_g.L; G.rs = bfhip_conv_g.rs; G.log2L = bfhip_conv_g.log2L; G.inited = true;
     const pid_t me = getpid();
     if (G.pid == me && G.stream) return true;
-    // first device use in this process (or a fork()ed child: start over, HIP does not survive)
-    G.pid = me;
-    G.stream = nullptr;
-    G.tw.clear(); G.buf.clear(); G.cap.clear(); G.d_flag = nullptr; G.d_over = nullptr;
-    for (int i = 0; i < 3; i++) { G.d_big[i] = nullptr; G.big_bytes[i] = 0; }
+    if (G.pid != 0 && G.pid != me) {
+        // HIP state does not survive fork(): a child of a process that already ran a device op
+        // through this library inherits a dead runtime.  Nothing the host does before the fork
+        // reaches a device op (those entry points are pure host code, host_ops.cpp), so this is a
+        // host bug: say so instead of hanging in the runtime.
+        fatal(106, "bfhip: the HIP runtime was initialised in process %d before fork(); device "
+                   "calls are only valid in the process that made the first one", (int)G.pid);
+        return false;
+    }
+    // first device use in this process
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         fatal(102, "bfhip: no HIP device available (there is no CPU fallback)");
         return false;
     }
+    G.pid = me;
     DCHK(hipStreamCreateWithFlags(&G.stream, hipStreamNonBlocking));
     DCHK(hipMalloc((void **)&G.d_flag, sizeof(int)));
     DCHK(hipMemset(G.d_flag, 0, sizeof(int)));
@@ -548,34 +533,11 @@ bool format_ok(const bfhip_buffer_format *bf) {
     return true;
 }
 
-struct TdConv { void *d_coeffs; int blocklen; };
-
-struct Plan { int order, invert; };
-
 }  // namespace
-
-struct _td_conv_t_ { TdConv v; };
 
 // ==================================================================== the 22 symbols
 
 extern "C" {
-
-int bfhip_convolver_last_fatal(void) { return G.last_fatal; }
-void bfhip_convolver_set_fatal_handler(void (*handler)(int, const char *)) { G.handler = handler; G.last_fatal = 0; }
-
-int convolver_init(const char config_filename[], int length, int realsize) {
-    (void)config_filename;                     /* FFTW wisdom: nothing to tune here */
-    if (realsize != 4 && realsize != 8) { fprintf(stderr, "Invalid real size %d.\n", realsize); return 0; }
-    int order = 0;
-    while ((1 << order) < length) order++;
-    if (length < 1 || (1 << order) != length) { fprintf(stderr, "Invalid length %d.\n", length); return 0; }
-    if (order > 20) { fprintf(stderr, "Invalid length %d (the device path supports up to 1048576).\n", length); return 0; }
-    G.L = length; G.rs = realsize; G.log2L = order; G.inited = true; G.last_fatal = 0;
-    G.pid = 0;                                 /* device comes up lazily, per process */
-    return 1;
-}
-
-int convolver_cbufsize(void) { return 2 * G.L * G.rs; }
 
 void convolver_raw2cbuf(void *rawbuf, void *cbuf, void *next_cbuf, struct bfhip_buffer_format *bf,
                         void (*postprocess)(void *, int, void *), void *pp_arg) {
@@ -603,8 +565,8 @@ static void fft_host(int log2c, bool inverse, void *in, void *out) {
     down(out, d, bytes);
 }
 
-void convolver_time2freq(void *input_cbuf, void *output_cbuf) { fft_host(G.log2L, false, input_cbuf, output_cbuf); }
-void convolver_freq2time(void *input_cbuf, void *output_cbuf) { fft_host(G.log2L, true, input_cbuf, output_cbuf); }
+void convolver_time2freq(void *input_cbuf, void *output_cbuf) { fft_host(bfhip_conv_g.log2L, false, input_cbuf, output_cbuf); }
+void convolver_freq2time(void *input_cbuf, void *output_cbuf) { fft_host(bfhip_conv_g.log2L, true, input_cbuf, output_cbuf); }
 
 void convolver_mixnscale(void *input_cbufs[], void *output_cbuf, double scales[], int n_bufs, int mixmode) {
     if (mixmode != CONVOLVER_MIXMODE_INPUT && mixmode != CONVOLVER_MIXMODE_OUTPUT) {
@@ -741,134 +703,27 @@ void convolver_cbuf2raw(void *cbuf, void *outbuf, struct bfhip_buffer_format *bf
     }
 }
 
-void *convolver_coeffs2cbuf(void *coeffs, int n_coeffs, double scale, void *optional_dest) {
-    if (!ensure_device()) return NULL;
-    const int len = n_coeffs > G.L ? G.L : (n_coeffs < 0 ? 0 : n_coeffs);
-    void *d_taps = scratch(0, (size_t)G.L * G.rs), *d_t = scratch(1, csz()), *d_out = scratch(2, csz());
-    if (!d_taps || !d_t || !d_out) return NULL;
-    if (len > 0 && !up(d_taps, coeffs, (size_t)len * G.rs)) return NULL;
-    per_type([&](auto t) {
-        using T = decltype(t);
-        hipLaunchKernelGGL(k_pad_scale<T>, dim3(grid(G.L)), dim3(256), 0, G.stream, (const T *)d_taps, len, (T)scale, (T *)d_t, G.L, G.d_flag);
-    });
-    int bad = 0;
-    if (!down(&bad, G.d_flag, sizeof(int))) return NULL;
-    if (bad) {
-        (void)hipMemset(G.d_flag, 0, sizeof(int));
-        fprintf(stderr, "NaN or Inf value among coefficients.\n");             /* :543-546 */
-        return NULL;
-    }
-    if (!dev_fft(G.log2L, false, d_t, d_t)) return NULL;
-    const double inv = 1.0 / (double)(2 * G.L);
-    void *p = d_t;
-    if (!dev_mix(&p, 1, d_out, &inv, CONVOLVER_MIXMODE_INPUT)) return NULL;
-    void *dest = optional_dest;
-    if (dest == NULL) {
-        if (posix_memalign(&dest, 32, csz()) != 0) { fatal(3, "Could not allocate memory."); return NULL; }
-        G.coeff_allocs.push_back(dest);          /* never freed, like the reference's */
-    }
-    if (!down(dest, d_out, csz())) return NULL;
-    return dest;
-}
-
-void convolver_runtime_coeffs2cbuf(void *src, void *dest) {
-    if (!ensure_device()) return;
-    const size_t half = (size_t)G.L * G.rs;
-    void *d_t = scratch(1, csz()), *d_out = scratch(2, csz());
-    if (!d_t || !d_out) return;
-    if (hipMemsetAsync(d_t, 0, half, G.stream) != hipSuccess) return;
-    if (!up((uint8_t *)d_t + half, src, half)) return;
-    if (!dev_fft(G.log2L, false, d_t, d_t)) return;
-    const double inv = 1.0 / (double)(2 * G.L);
-    void *p = d_t;
-    if (!dev_mix(&p, 1, d_out, &inv, CONVOLVER_MIXMODE_INPUT)) return;
-    down(dest, d_out, csz());
-}
-
-int convolver_verify_cbuf(void *cbufs[], int n_cbufs) {
-    /* a scan of host memory for NaN/Inf: validation, not path arithmetic -- stays on the host */
-    for (int n = 0; n < n_cbufs; n++) {
-        for (int i = 0; i < 2 * G.L; i++) {
-            const double v = G.rs == 4 ? (double)((float *)cbufs[n])[i] : ((double *)cbufs[n])[i];
-            if (!std::isfinite(v)) { fprintf(stderr, "NaN or Inf value among coefficients.\n"); return 0; }
-        }
-    }
-    return 1;
-}
-
-void convolver_debug_dump_cbuf(const char filename[], void *cbufs[], int n_cbufs) {
-    FILE *stream = fopen(filename, "wt");
-    if (stream == NULL) { fprintf(stderr, "Could not open \"%s\" for writing: %s", filename, strerror(errno)); return; }
-    std::vector<unsigned char> tmp(csz());
-    double one = 1.0;
-    for (int n = 0; n < n_cbufs; n++) {
-        convolver_mixnscale(&cbufs[n], tmp.data(), &one, 1, CONVOLVER_MIXMODE_OUTPUT);
-        convolver_freq2time(tmp.data(), tmp.data());
-        for (int i = 0; i < G.L; i++) {
-            const double v = G.rs == 4 ? (double)((float *)tmp.data())[G.L + i] : ((double *)tmp.data())[G.L + i];
-            fprintf(stream, "%.16e\n", v);
-        }
-    }
-    fclose(stream);
-}
-
-void *convolver_fftplan(int order, int invert, int inplace) {
-    (void)inplace;
-    static std::map<std::pair<int, int>, Plan *> plans;     /* "Do not free it" (convolver.h:128) */
-    auto key = std::make_pair(order, invert ? 1 : 0);
-    auto it = plans.find(key);
-    if (it != plans.end()) return it->second;
-    Plan *p = new Plan{order, invert ? 1 : 0};
-    plans[key] = p;
-    return p;
-}
-
-void bfhip_fftplan_execute(void *plan, void *in, void *out) {
-    const Plan *p = (const Plan *)plan;
-    if (p == NULL || p->order < 1) { fatal(104, "bfhip: invalid FFT plan"); return; }
-    fft_host(p->order - 1, p->invert != 0, in, out);
-}
-
-int convolver_td_block_length(int n_coeffs) {
-    if (n_coeffs < 1) return -1;
-    int o = 0;
-    while ((1 << o) < n_coeffs) o++;                          /* 1 << log2_roof(n) */
-    return 1 << o;
-}
-
-td_conv_t *convolver_td_new(void *coeffs, int n_coeffs) {
-    const int blocklen = convolver_td_block_length(n_coeffs);
-    if (blocklen == -1 || !ensure_device()) return NULL;
-    int lg = 0;
-    while ((1 << lg) < blocklen) lg++;
-    const size_t bytes = (size_t)2 * blocklen * G.rs;
-    std::vector<unsigned char> h(bytes, 0);                    /* [blocklen zeros | coeffs | zeros] */
-    memcpy(h.data() + (size_t)blocklen * G.rs, coeffs, (size_t)n_coeffs * G.rs);
-    td_conv_t *tdc = new td_conv_t();
-    tdc->v.blocklen = blocklen;
-    if (hipMalloc(&tdc->v.d_coeffs, bytes) != hipSuccess) { fatal(103, "bfhip: out of device memory"); delete tdc; return NULL; }
-    if (!up(tdc->v.d_coeffs, h.data(), bytes)) return NULL;
-    if (!dev_fft(lg, false, tdc->v.d_coeffs, tdc->v.d_coeffs)) return NULL;
-    per_type([&](auto t) {
-        using T = decltype(t);
-        hipLaunchKernelGGL(k_scale_all<T>, dim3(grid(2 * blocklen)), dim3(256), 0, G.stream, (T *)tdc->v.d_coeffs, (T)1.0 / (T)(blocklen << 1), 2 * blocklen);
-    });
-    (void)hipStreamSynchronize(G.stream);
-    return tdc;
-}
-
 void convolver_td_convolve(td_conv_t *tdc, void *overlap_block) {
     if (tdc == NULL || !ensure_device()) return;
-    const int size = tdc->v.blocklen << 1;
+    const int size = tdc->blocklen << 1;
     int lg = 0;
-    while ((1 << lg) < tdc->v.blocklen) lg++;
+    while ((1 << lg) < tdc->blocklen) lg++;
     const size_t bytes = (size_t)size * G.rs;
+    if (tdc->d_coeffs == nullptr || tdc->d_pid != G.pid) {
+        /* the filter's spectrum was computed on the host by convolver_td_new() (delay.c builds
+           its filters in the parent, before the fork): first use in this process uploads it */
+        void *d = nullptr;
+        if (hipMalloc(&d, bytes) != hipSuccess) { fatal(103, "bfhip: out of device memory"); return; }
+        if (!up(d, tdc->h_coeffs, bytes)) return;
+        tdc->d_coeffs = d;
+        tdc->d_pid = G.pid;
+    }
     void *d = scratch(0, bytes);
     if (!d || !up(d, overlap_block, bytes)) return;
     if (!dev_fft(lg, false, d, d)) return;
     per_type([&](auto t) {
         using T = decltype(t);
-        hipLaunchKernelGGL(k_conv_ordered<T>, dim3(grid(size / 2 + 1)), dim3(256), 0, G.stream, (T *)d, (const T *)tdc->v.d_coeffs, size);
+        hipLaunchKernelGGL(k_conv_ordered<T>, dim3(grid(size / 2 + 1)), dim3(256), 0, G.stream, (T *)d, (const T *)tdc->d_coeffs, size);
     });
     if (!dev_fft(lg, true, d, d)) return;
     down(overlap_block, d, bytes);

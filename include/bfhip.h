@@ -143,6 +143,29 @@ int bfhip_engine_add_coeff_processed(bfhip_engine *e, const void *cbufs, int n_b
 /* the inverse: a loaded set back in that layout (bfaccess->coeffs_data, debug dumps, writing
    "processed" files); cbufs must hold n_blocks * 2L reals.  Returns n_blocks. */
 int bfhip_engine_read_coeff_processed(bfhip_engine *e, int coeff, void *cbufs);
+/* The same for what an UNMODIFIED bfconf holds: bfconf->coeffs_data[c][0..n_blocks) are separate
+   allocations (bfconf.c:1994-2009: one convolver_coeffs2cbuf() result, or one slice of a
+   shared-memory segment, per block).  watch != 0: the set may be rewritten at run time by another
+   process (bflogic_eq renders into coeffs_data[c][i] in ITS process through
+   bfaccess->convolver_coeffs2cbuf, rendereq.h:87-91); the engine remembers the host address of
+   every block and, at the start of each block, re-uploads the ones whose change notice moved --
+   see bfhip_coeff_mark_dirty() below.  The pointers must stay valid for the engine's life. */
+int bfhip_engine_add_coeff_processed_blocks(bfhip_engine *e, void *const cbufs[], int n_blocks,
+                                            int watch);
+/* re-upload one partition of a loaded set from a cbuf in the reference's layout now (cbuf NULL:
+   from the address given to add_coeff_processed_blocks) */
+int bfhip_engine_refresh_coeff_processed(bfhip_engine *e, int coeff, int block, const void *cbuf);
+/* what every block entry point does first when a watched set exists: returns how many
+   partitions were re-uploaded (>= 0) or an error */
+int bfhip_engine_poll_coeff_changes(bfhip_engine *e);
+/* Cross-process change notices.  convolver_init() (parent, before the fork) creates a small
+   MAP_SHARED table; every process forked afterwards shares it.  bfhip_coeff_mark_dirty(cbuf)
+   bumps the generation of the cbuf at that ADDRESS (the same in all processes: coefficient
+   memory is allocated before the fork); this library's convolver_runtime_coeffs2cbuf() calls it
+   on its `dest`, so an unmodified bflogic_eq is covered.  A module that writes coefficient
+   memory by other means calls it itself.  Pure host code, no HIP. */
+void bfhip_coeff_mark_dirty(const void *cbuf);
+unsigned long long bfhip_coeff_dirty_sequence(void);
 /* run-time replacement of one partition = convolver_runtime_coeffs2cbuf
    (fftw_convolver.c:575-596) as used by bflogic_eq (rendereq.h:87-91): L reals */
 int bfhip_engine_update_coeff_block(bfhip_engine *e, int coeff, int block, const void *taps);

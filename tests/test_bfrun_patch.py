@@ -1,0 +1,62 @@
+"""CPU, build container only: the one host change the drop-in needs is a REAL patch
+(patches/bfrun-bfhip.diff, SURVEY 8b "the one host patch", bfrun.c:1493-2008).  It is applied
+here to a temporary copy of the reference's bfrun.c and the result is compiled with
+`gcc -fsyntax-only -Wall` against the reference's own headers and include/bfhip.h -- with and
+without -DBF_HAVE_BFHIP.  Nothing from the reference enters the repository or travels to the
+GPU box (where /root/reference does not exist and this test is skipped)."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+PATCH = os.path.join(ROOT, "patches", "bfrun-bfhip.diff")
+
+pytestmark = pytest.mark.skipif(not os.path.exists(os.path.join(REF, "bfrun.c")),
+                                reason="the reference tree only exists in the build container")
+
+
+def _apply(tmp_path):
+    work = tmp_path / "host"
+    work.mkdir()
+    shutil.copy(os.path.join(REF, "bfrun.c"), work / "bfrun.c")
+    r = subprocess.run(["patch", "-p1", "--no-backup-if-mismatch", "-i", PATCH], cwd=work,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "FAILED" not in r.stdout and "fuzz" not in r.stdout, r.stdout
+    return work
+
+
+def _syntax(work, defines):
+    return subprocess.run(["gcc", "-fsyntax-only", "-Wall", "-Werror=implicit-function-declaration",
+                           "-Werror=incompatible-pointer-types", "-Werror=int-conversion"] + defines +
+                          ["-I" + REF, "-I" + os.path.join(ROOT, "include"), "bfrun.c"],
+                          cwd=work, capture_output=True, text=True)
+
+
+def test_patch_applies_and_compiles_against_the_reference_headers(tmp_path):
+    work = _apply(tmp_path)
+    on = _syntax(work, ["-DBF_HAVE_BFHIP"])
+    assert on.returncode == 0, on.stderr[-3000:]
+    assert "warning" not in on.stderr, on.stderr[-3000:]
+    off = _syntax(work, [])                              # without the define nothing changes
+    assert off.returncode == 0, off.stderr[-3000:]
+    src = (work / "bfrun.c").read_text()
+    # the fused call sits between the two timestamps the survey names, once
+    body = src[src.index("\ttimestamp(&t3);"):src.index("\ttimestamp(&t4);")]
+    assert body.count("bfhip_period(") == 1 and "goto bfhip_period_done;" in body
+    # every bfhip_* function the patch calls is declared in include/bfhip.h
+    import re
+    called = set(re.findall(r"\b(bfhip_(?:engine|coeff)_[a-z_]+)\s*\(", src))
+    header = open(os.path.join(ROOT, "include", "bfhip.h")).read()
+    assert called and all(c in header for c in called), sorted(c for c in called if c not in header)
+
+
+def test_committed_patch_is_what_the_generator_produces(tmp_path):
+    before = open(PATCH).read()
+    r = subprocess.run(["python3", os.path.join(ROOT, "tools", "make_bfrun_patch.py"), REF],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert open(PATCH).read() == before

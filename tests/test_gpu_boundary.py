@@ -1,0 +1,249 @@
+"""GPU: the corners of the drop-in boundary that round 1 left without a test.
+
+ * convolver_cbuf2raw(apply_dither = 1) from a C host that owns the dither tables, against the
+   goldens the reference's own dither code produced (tests/golden/ref_dither_*.npz);
+ * convolver_raw2cbuf with a `postprocess` callback (how delay.c hooks the sub-sample delay in,
+   bfrun.c:1503-1508);
+ * coefficient sets handed over the way an UNMODIFIED bfconf holds them -- one allocation per
+   block (bfconf.c:1994-2009) -- and rewritten at run time from ANOTHER PROCESS the way
+   bflogic_eq does it (rendereq.h:87-91), picked up by the engine at the next block;
+ * the fork guard: a device op in a child of a process that already used the device fails
+   cleanly instead of hanging in a dead runtime."""
+import ctypes as C
+import mmap
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import bforacle as bo
+import cases
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class SampleFormat(C.Structure):
+    _fields_ = [("isfloat", C.c_int), ("swap", C.c_int), ("bytes", C.c_int), ("sbytes", C.c_int),
+                ("scale", C.c_double), ("format", C.c_int)]
+
+
+class BufferFormat(C.Structure):
+    _fields_ = [("sf", SampleFormat), ("sample_spacing", C.c_int), ("byte_offset", C.c_int)]
+
+
+@pytest.fixture()
+def cv(hip):
+    L = hip.lib()
+    L.convolver_coeffs2cbuf.restype = C.c_void_p
+    L.convolver_coeffs2cbuf.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p]
+    L.convolver_runtime_coeffs2cbuf.argtypes = [C.c_void_p, C.c_void_p]
+    L.convolver_raw2cbuf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(BufferFormat), C.c_void_p, C.c_void_p]
+    return L
+
+
+@pytest.mark.parametrize("rs,tag", [(8, "f64"), (4, "f32")])
+def test_cbuf2raw_with_dither_from_a_c_host_vs_reference_goldens(hip, tmp_path, rs, tag):
+    g = np.load(os.path.join(G, "ref_dither_%s.npz" % tag))
+    x = g["x"]
+    n_blk, n_ch, L = x.shape
+    table = g["table_head"]
+    assert len(table) == int(g["table_size"])             # the whole table is in the fixture
+    spacing = (len(table) - 1) // n_ch
+    exe = str(tmp_path / "dither_host")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "chost", "dither_host.c"), "-o", exe,
+                           "-L" + os.path.join(ROOT, "brutefir_amd"), "-lbfhip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "brutefir_amd")])
+    with open(tmp_path / "in.bin", "wb") as f:
+        f.write(np.array([rs, L, n_ch, n_blk, len(table), spacing], np.int32).tobytes())
+        f.write(table.tobytes())
+        f.write(np.ascontiguousarray(x).tobytes())
+    r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")],
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr
+    out = open(tmp_path / "out.bin", "rb").read()
+    n = n_blk * n_ch * L
+    raw = np.frombuffer(out, np.int16, n).reshape(n_blk, n_ch, L)
+    ptrs = np.frombuffer(out, np.int32, n_blk * n_ch, 2 * n).reshape(n_blk, n_ch)
+    of = np.frombuffer(out, np.float64, n_ch * 4, 2 * n + 4 * n_blk * n_ch).reshape(n_ch, 4)
+    # the integer bookkeeping (table walk incl. the wrap branch, dither.h:28-38) is exact
+    assert np.array_equal(ptrs, g["randtab_ptr"])
+    if rs == 8:
+        assert np.array_equal(raw, g["raw"])              # bit-exact in the working precision
+        assert np.array_equal(of, g["of"])
+    else:
+        # float32: the error-feedback chain is the same arithmetic without contraction; allow the
+        # 1 LSB the engine-level test allows and require the clip accounting to agree
+        assert np.abs(raw.astype(np.int32) - g["raw"].astype(np.int32)).max() <= 1
+        assert of[:, 0].tolist() == g["of"][:, 0].tolist()
+
+
+@pytest.mark.parametrize("rs", [4, 8])
+def test_raw2cbuf_runs_the_postprocess_callback_on_the_converted_block(cv, rs):
+    dt = np.float32 if rs == 4 else np.float64
+    L = 256
+    assert cv.convolver_init(None, L, rs) == 1
+    seen = []
+    CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p)
+
+    def post(realbuf, n_samples, arg):
+        seen.append((n_samples, arg))
+        a = np.ctypeslib.as_array(C.cast(realbuf, C.POINTER(C.c_float if rs == 4 else C.c_double)), (n_samples,))
+        a *= 2                                            # what apply_subdelay would filter in place
+
+    cb = CB(post)
+    rng = np.random.default_rng(5)
+    raw = rng.integers(-30000, 30000, (L, 3), dtype=np.int16)      # 3 interleaved S16 channels
+    bf = BufferFormat(SampleFormat(0, 0, 2, 2, 1.0 / 32768, 0), 3, 2)   # channel 1
+    cbuf, nxt = np.zeros(2 * L, dt), np.zeros(2 * L, dt)
+    token = C.c_int(42)
+    cv.convolver_raw2cbuf(p(raw), p(cbuf), p(nxt), C.byref(bf), cb, C.addressof(token))
+    assert seen == [(L, C.addressof(token))]
+    want = raw[:, 1].astype(dt) * 2
+    assert np.array_equal(nxt[:L], want)                  # filtered block kept for the next call
+    assert np.array_equal(cbuf[L:], want)                 # and copied behind the previous one (:193)
+    assert not cbuf[:L].any()
+
+
+def _render(cv, taps, L, rs, dest_addr):
+    dt = np.float32 if rs == 4 else np.float64
+    t = np.ascontiguousarray(taps, dt)
+    assert cv.convolver_coeffs2cbuf(p(t), len(t), 1.0, C.c_void_p(dest_addr)) == dest_addr
+
+
+@pytest.mark.parametrize("rs", [4, 8])
+def test_coefficient_blocks_in_separate_allocations(hip, cv, rs):
+    """bfconf->coeffs_data[c][i] are separate buffers prepared by convolver_coeffs2cbuf in the
+    parent (host code, no HIP); the engine takes them as they are"""
+    dt = np.float32 if rs == 4 else np.float64
+    L, N, I, O = 512, 3, 2, 2
+    assert cv.convolver_init(None, L, rs) == 1
+    e = hip.Engine(L, N, rs, I, O)
+    oe = bo.Engine(L, N, rs, I, O)
+    for x in (e, oe):
+        x.set_interleaved(0, "S16_LE")
+        x.set_interleaved(1, "FLOAT_LE" if rs == 4 else "FLOAT64_LE")
+    keep = []
+    for o in range(O):
+        for i in range(I):
+            h = cases.make_ir(np.random.default_rng(9 + o * I + i), L * N - 100, I).astype(dt)
+            blocks = []
+            for b in range(N):
+                buf = np.empty(2 * L, dt)                 # one allocation per block
+                _render(cv, h[b * L:(b + 1) * L], L, rs, buf.ctypes.data)
+                blocks.append(buf)
+            keep.append(blocks)
+            c = e.add_coeff_processed_blocks([b.ctypes.data for b in blocks])
+            e.add_filter(in_ch=[i], out_ch=[o], coeff=c)
+            oe.add_filter(in_ch=[i], out_ch=[o], coeff=oe.add_coeff(h))
+    e.finalize()
+    for blk in cases.raw_blocks(3, N + 3, L, I, "S16_LE"):
+        st, got = e.block(blk)
+        _, want = oe.block(blk)
+        assert st == 0
+        assert cases.rel_rms(np.frombuffer(got.tobytes(), dt), np.frombuffer(want.tobytes(), dt)) <= (1e-5 if rs == 4 else 1e-12)
+
+
+@pytest.mark.parametrize("rs", [4, 8])
+def test_partition_rewritten_by_another_process_is_applied_at_the_next_block(hip, cv, rs):
+    """The bflogic_eq flow with nothing modified: the module process renders new taps into the
+    shared coefficient memory through bfaccess->convolver_coeffs2cbuf
+    (= convolver_runtime_coeffs2cbuf, rendereq.h:87-91); that call is pure host code here and
+    leaves a change notice; the filter process's engine re-uploads the partition at the start of
+    its next block.  Reference behaviour to match: from that block on ALL history is convolved
+    with the new partitions (the filter loop just reads coeffs_data, bfrun.c:1745-1770)."""
+    dt = np.float32 if rs == 4 else np.float64
+    L, N = 256, 4
+    tol = 1e-5 if rs == 4 else 1e-12
+    assert cv.convolver_init(None, L, rs) == 1            # parent, "before the fork": creates the notice table
+    shm = mmap.mmap(-1, N * 2 * L * rs)                   # MAP_SHARED, like the coefficient segment
+    base = np.frombuffer(shm, dt)
+    addr = [base[b * 2 * L:].ctypes.data for b in range(N)]
+    h0 = cases.make_ir(np.random.default_rng(1), L * N, 1).astype(dt)
+    h1 = h0.copy()
+    h1[L:3 * L] = cases.make_ir(np.random.default_rng(2), 2 * L, 1).astype(dt)      # partitions 1 and 2 change
+    for b in range(N):
+        _render(cv, h0[b * L:(b + 1) * L], L, rs, addr[b])
+    e = hip.Engine(L, N, rs, 1, 1)
+    oe = bo.Engine(L, N, rs, 1, 1)
+    for x in (e, oe):
+        x.set_interleaved(0, "S16_LE")
+        x.set_interleaved(1, "FLOAT_LE" if rs == 4 else "FLOAT64_LE")
+    c = e.add_coeff_processed_blocks(addr, watch=True)
+    e.add_filter(in_ch=[0], out_ch=[0], coeff=c)
+    e.finalize()
+    oc0, oc1 = oe.add_coeff(h0), oe.add_coeff(h1)
+    oe.add_filter(in_ch=[0], out_ch=[0], coeff=oc0)
+    blocks = cases.raw_blocks(8, 2 * N + 4, L, 1, "S16_LE")
+    switch_at = N + 2
+
+    def step(k):
+        st, got = e.block(blocks[k])
+        _, want = oe.block(blocks[k])
+        assert st == 0
+        return cases.rel_rms(np.frombuffer(got.tobytes(), dt), np.frombuffer(want.tobytes(), dt))
+
+    for k in range(switch_at):
+        assert step(k) <= tol, k
+    assert e.poll_coeff_changes() == 0
+    pid = os.fork()                                       # the module process: never touches HIP
+    if pid == 0:
+        try:
+            for b in (1, 2):
+                src = np.ascontiguousarray(h1[b * L:(b + 1) * L])
+                cv.convolver_runtime_coeffs2cbuf(p(src), C.c_void_p(addr[b]))
+        finally:
+            os._exit(0)
+    assert os.waitpid(pid, 0)[1] == 0
+    oe.set_coeff(0, oc1)
+    errs = [step(k) for k in range(switch_at, len(blocks))]
+    assert max(errs) <= tol, errs
+    assert e.poll_coeff_changes() == 0                    # both notices were consumed by the block call
+    # and the device copy now equals what the host memory holds
+    got = e.read_coeff_processed(c, N)
+    assert np.array_equal(got.ravel(), base)
+
+
+def test_device_op_in_a_child_of_a_device_process_fails_cleanly(hip):
+    """HIP state does not survive fork(): instead of hanging in the inherited runtime the library
+    reports fatal code 106.  (Run in a fresh interpreter: the child must be a fork of a process
+    whose FIRST device op went through this library.)"""
+    code = r'''
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, %r)
+import brutefir_amd as bf
+L = bf.lib()
+for f in ("convolver_time2freq",):
+    getattr(L, f).argtypes = [C.c_void_p, C.c_void_p]
+assert L.convolver_init(None, 64, 4) == 1
+x = np.ones(128, np.float32); y = np.empty(128, np.float32)
+L.convolver_time2freq(x.ctypes.data, y.ctypes.data)          # parent initialises HIP
+assert abs(y[0] - 128.0) < 1e-3
+r, w = os.pipe()
+pid = os.fork()
+if pid == 0:
+    HANDLER = C.CFUNCTYPE(None, C.c_int, C.c_char_p)
+    msgs = []
+    h = HANDLER(lambda code, msg: msgs.append((code, msg)))
+    L.bfhip_convolver_set_fatal_handler(h)
+    L.convolver_time2freq(x.ctypes.data, y.ctypes.data)      # must not touch the dead runtime
+    os.write(w, ("%%d" %% L.bfhip_convolver_last_fatal()).encode())
+    os._exit(0)
+os.close(w)
+got = os.read(r, 16).decode()
+os.waitpid(pid, 0)
+print("child fatal code", got)
+assert got == "106", got
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "child fatal code 106" in r.stdout
