@@ -170,6 +170,7 @@ def main():
         np.savez_compressed(os.path.join(HERE, "ref_conv_%s.npz" % tag), **conversions(R, rs, 200 + rs))
     if len(sys.argv) == 1:
         delay_and_window(R)
+        xtc_taps()
     # dither state is process-global in the reference: one precision per process
     which = sys.argv[1] if len(sys.argv) > 1 else None
     if which in ("f32", "f64"):
@@ -180,6 +181,17 @@ def main():
         for w in ("f32", "f64"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), w])
     print("golden vectors written to", HERE)
+
+
+
+def xtc_taps():
+    """The two coefficient files xtc_config names (`filename: "directpath.txt"` /
+    "crosspath.txt", 4096 text taps each): DATA the reference ships, stored as a fixture so that
+    the GPU box (no /root/reference) can run the reference's own cross-talk canceller."""
+    ref = "/root/reference"
+    np.savez_compressed(os.path.join(HERE, "xtc_taps.npz"),
+                        directpath=np.loadtxt(os.path.join(ref, "directpath.txt")),
+                        crosspath=np.loadtxt(os.path.join(ref, "crosspath.txt")))
 
 
 if __name__ == "__main__":

@@ -247,3 +247,16 @@ def test_subsample_delay_is_a_fractional_shift(rs, tol):
     r = np.random.default_rng(1).standard_normal((nblk * L, 1))
     y2 = np.concatenate([e2.block(r[b * L:(b + 1) * L])[1].view(np.float64) for b in range(nblk)])
     assert np.abs(y2[half:] - r[:-half, 0]).max() < tol
+
+
+@pytest.mark.parametrize("rs,tol", [(4, 2e-6), (8, 1e-13)])
+def test_delay_cascade_crossfade_network_against_numpy(rs, tol):
+    """the oracle's cross-fade (A7), cascade evaluation (A8) and block bookkeeping (A12) cannot be
+    pinned by reference output here (FFTW absent): pin them by an independent float64 numpy model
+    of the whole network instead; the same model checks the HIP engine in tests/test_gpu_numpy.py"""
+    y, want, L, sw = cases.fade_cascade_network(bo.Engine, rs)
+    for ch in range(2):
+        assert cases.rel_rms(y[:, ch], want[:, ch]) <= tol, ch
+    for b in (sw - 1, sw, sw + 1):
+        s = slice(b * L, (b + 1) * L)
+        assert cases.rel_rms(y[s, 0], want[s, 0]) <= 2 * tol, b
