@@ -109,6 +109,7 @@ def lib():
     L.bfhip_engine_set_fscale.argtypes = [vp, ci, ci, cd]
     L.bfhip_engine_block.argtypes = [vp, vp, vp, C.POINTER(Overflow)]
     L.bfhip_engine_block_dev.argtypes = [vp, vp, vp]
+    L.bfhip_engine_block_dev_ev.argtypes = [vp, vp, vp, vp, vp]
     L.bfhip_engine_sync.argtypes = [vp]
     L.bfhip_engine_inputs_dev.argtypes = [vp, vp]
     L.bfhip_engine_mac_dev.argtypes = [vp, vp]
@@ -329,6 +330,15 @@ class Engine:
 
     def block_dev(self, rawin_dev, rawout_dev):
         _check(lib().bfhip_engine_block_dev(self.h, _ptr(rawin_dev), _ptr(rawout_dev)))
+
+    def block_dev_ev(self, rawin_dev, rawout_dev, in_ready=None, out_done=None):
+        """in_ready / out_done: hipEvent_t handles (ints), e.g. torch.cuda.Event().cuda_event"""
+        _check(lib().bfhip_engine_block_dev_ev(self.h, _ptr(rawin_dev), _ptr(rawout_dev),
+                                               C.c_void_p(in_ready) if in_ready else None,
+                                               C.c_void_p(out_done) if out_done else None))
+
+    def set_overlap(self, mode):
+        _check(lib().bfhip_engine_set_overlap(self.h, mode))
 
     def prewarm(self):
         _check(lib().bfhip_engine_prewarm(self.h))

@@ -17,6 +17,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <map>
 #include <string>
 #include <vector>
@@ -67,6 +68,43 @@ struct Coeff {
     // where each block lives on the host, and the change-notice generation last uploaded
     std::vector<const void *> watch_src;
     std::vector<uint64_t> watch_gen;
+};
+
+// Pinned staging for the small per-block tables (N:1 channel jobs, delay-line moves, sub-sample
+// delay jobs) that go to the device with every block: K slots, one per block in flight, so the
+// upload is truly asynchronous and the host copy outlives the call that queued it.
+struct Stage {
+    static constexpr int K = 4;
+    uint8_t *base = nullptr;
+    size_t slot = 0;
+    int turn = 0;
+    hipEvent_t done[K] = {nullptr, nullptr, nullptr, nullptr};
+    bool pending[K] = {false, false, false, false};
+
+    hipError_t init(size_t slot_bytes) {
+        slot = (slot_bytes + 63) & ~(size_t)63;
+        hipError_t r = hipHostMalloc((void **)&base, slot * K, hipHostMallocDefault);
+        for (int i = 0; i < K && r == hipSuccess; i++) r = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+        return r;
+    }
+    void release() {
+        for (int i = 0; i < K; i++) if (done[i]) { (void)hipEventDestroy(done[i]); done[i] = nullptr; }
+        if (base) { (void)hipHostFree(base); base = nullptr; }
+    }
+    // next slot, free again once the copy queued from it K blocks ago has run
+    hipError_t take(uint8_t **p) {
+        const int i = turn++ % K;
+        if (pending[i]) { const hipError_t r = hipEventSynchronize(done[i]); if (r != hipSuccess) return r; pending[i] = false; }
+        *p = base + (size_t)i * slot;
+        return hipSuccess;
+    }
+    // the copies out of the slot handed out last have been queued on st
+    hipError_t queued(hipStream_t st) {
+        const int i = (turn - 1) % K;
+        const hipError_t r = hipEventRecord(done[i], st);
+        pending[i] = r == hipSuccess;
+        return r;
+    }
 };
 
 struct Filter {
@@ -258,10 +296,9 @@ struct bfhip_engine {
     std::vector<int> vin_list;             // virtual inputs that share a physical one
     std::vector<std::vector<int>> vout_groups;   // members of every shared physical output
     uint8_t *d_incopy = nullptr;           // [vin_list.size()][L * 8]
-    void *d_vjobs = nullptr;               // per-block job/op tables (device)
-    void *h_vjobs = nullptr;               // pinned staging ring
+    void *d_vjobs = nullptr;               // per-block job/op tables (device): input half | output half
     size_t vjobs_slot = 0;
-    int vjobs_turn = 0;
+    Stage st_vin, st_vout, st_sd[2];       // their pinned staging, one slot per block in flight
     bool has_vchan = false;
 
     // sub-sample delay (sdf_length / sdf_beta / per-channel subdelay; delay.c:416-505)
@@ -1149,7 +1186,11 @@ int do_subdelay_t(bfhip_engine *e, int io, const void *rawin_dev) {
         jobs.push_back(j);
     }
     if (jobs.empty()) return BFHIP_OK;
-    HIPCHK(hipMemcpyAsync(e->d_sdjobs[io], jobs.data(), jobs.size() * sizeof(SdJob<T>), hipMemcpyHostToDevice, e->ls));
+    uint8_t *pin = nullptr;
+    HIPCHK(e->st_sd[io].take(&pin));
+    memcpy(pin, jobs.data(), jobs.size() * sizeof(SdJob<T>));
+    HIPCHK(hipMemcpyAsync(e->d_sdjobs[io], pin, jobs.size() * sizeof(SdJob<T>), hipMemcpyHostToDevice, e->ls));
+    HIPCHK(e->st_sd[io].queued(e->ls));
     const size_t lds = (size_t)(e->sd_bs + e->L) * sizeof(T);
     auto k = subdelay_fir_kernel<T>;
     HIPCHK(allow_lds(k, lds));
@@ -1184,8 +1225,12 @@ int do_vin(bfhip_engine *e, const void *rawin_dev) {
     const size_t jb = jobs.size() * sizeof(VInJob), ob = ops.size() * sizeof(ByteOp);
     if (jb + ob > e->vjobs_slot) return fail(BFHIP_ESTATE, "virtual-channel job table overflow");
     unsigned char *dev = (unsigned char *)e->d_vjobs;
-    HIPCHK(hipMemcpyAsync(dev, jobs.data(), jb, hipMemcpyHostToDevice, e->ls));
-    if (ob) HIPCHK(hipMemcpyAsync(dev + jb, ops.data(), ob, hipMemcpyHostToDevice, e->ls));
+    uint8_t *pin = nullptr;
+    HIPCHK(e->st_vin.take(&pin));
+    memcpy(pin, jobs.data(), jb);
+    if (ob) memcpy(pin + jb, ops.data(), ob);
+    HIPCHK(hipMemcpyAsync(dev, pin, jb + ob, hipMemcpyHostToDevice, e->ls));
+    HIPCHK(e->st_vin.queued(e->ls));
     hipLaunchKernelGGL(vchan_in_kernel<0>, dim3((unsigned)jobs.size()), dim3(256), 0, e->ls,
                        (const VInJob *)dev, (const ByteOp *)(dev + jb), (const uint8_t *)rawin_dev, e->L);
     HIPCHK(hipGetLastError());
@@ -1218,9 +1263,13 @@ int do_vout(bfhip_engine *e, void *rawout_dev) {
     const size_t jb = jobs.size() * sizeof(VOutJob), mb = mem.size() * sizeof(VOutMember), ob = ops.size() * sizeof(ByteOp);
     if (jb + mb + ob > e->vjobs_slot) return fail(BFHIP_ESTATE, "virtual-channel job table overflow");
     unsigned char *dev = (unsigned char *)e->d_vjobs + e->vjobs_slot;      // second half: output side
-    HIPCHK(hipMemcpyAsync(dev, jobs.data(), jb, hipMemcpyHostToDevice, e->ls));
-    HIPCHK(hipMemcpyAsync(dev + jb, mem.data(), mb, hipMemcpyHostToDevice, e->ls));
-    if (ob) HIPCHK(hipMemcpyAsync(dev + jb + mb, ops.data(), ob, hipMemcpyHostToDevice, e->ls));
+    uint8_t *pin = nullptr;
+    HIPCHK(e->st_vout.take(&pin));
+    memcpy(pin, jobs.data(), jb);
+    memcpy(pin + jb, mem.data(), mb);
+    if (ob) memcpy(pin + jb + mb, ops.data(), ob);
+    HIPCHK(hipMemcpyAsync(dev, pin, jb + mb + ob, hipMemcpyHostToDevice, e->ls));
+    HIPCHK(e->st_vout.queued(e->ls));
     if (e->rs == 4)
         hipLaunchKernelGGL(vchan_out_kernel<float>, dim3((unsigned)jobs.size()), dim3(256), 0, e->ls,
                            (const VOutJob *)dev, (const VOutMember *)(dev + jb), (const ByteOp *)(dev + jb + mb),
@@ -1515,6 +1564,7 @@ int subdelay_setup(bfhip_engine *e) {
         HIPCHK(hipMalloc(&e->d_sd_rest[io], (size_t)n_slots[io] * e->sd_bs * e->rs));
         HIPCHK(hipMemset(e->d_sd_rest[io], 0, (size_t)n_slots[io] * e->sd_bs * e->rs));
         HIPCHK(hipMalloc(&e->d_sdjobs[io], (size_t)n_slots[io] * 128));
+        HIPCHK(e->st_sd[io].init((size_t)n_slots[io] * 128));
     }
     if (n_slots[0] > 0) {
         HIPCHK(hipMalloc(&e->d_sdin, (size_t)n_slots[0] * e->L * e->rs));
@@ -1616,6 +1666,7 @@ void bfhip_engine_destroy(bfhip_engine *e) {
       for (void *q : sp) if (q) (void)hipFree(q); }
     rt_release(e);
     if (e->d_vjobs) (void)hipFree(e->d_vjobs);
+    e->st_vin.release(); e->st_vout.release(); e->st_sd[0].release(); e->st_sd[1].release();
     if (e->d_Zp2) (void)hipFree(e->d_Zp2);
     for (int i = 0; i < 2; i++) {
         if (e->ev_in[i]) (void)hipEventDestroy(e->ev_in[i]);
@@ -2142,6 +2193,8 @@ int bfhip_engine_finalize(bfhip_engine *e) {
             }
             e->vjobs_slot = (n_ops_max + 8) * sizeof(ByteOp) + (e->n_ch[0] + e->n_ch[1] + 8) * 64;
             HIPCHK(hipMalloc(&e->d_vjobs, 2 * e->vjobs_slot));
+            HIPCHK(e->st_vin.init(e->vjobs_slot));
+            HIPCHK(e->st_vout.init(e->vjobs_slot));
             e->vline[0].resize(e->n_ch[0]); e->vline[1].resize(e->n_ch[1]);
         }
         // outputs K3 does not requantise itself (the dither pass or the N:1 mix does, from the time
@@ -2355,7 +2408,20 @@ int bfhip_engine_advance(bfhip_engine *e) {
     return BFHIP_OK;
 }
 
+static int block_dev_impl(bfhip_engine *e, const void *rawin_dev, void *rawout_dev,
+                          hipEvent_t in_ready, hipEvent_t out_done);
+
 int bfhip_engine_block_dev(bfhip_engine *e, const void *rawin_dev, void *rawout_dev) {
+    return block_dev_impl(e, rawin_dev, rawout_dev, nullptr, nullptr);
+}
+
+int bfhip_engine_block_dev_ev(bfhip_engine *e, const void *rawin_dev, void *rawout_dev,
+                              void *in_ready_event, void *out_done_event) {
+    return block_dev_impl(e, rawin_dev, rawout_dev, (hipEvent_t)in_ready_event, (hipEvent_t)out_done_event);
+}
+
+static int block_dev_impl(bfhip_engine *e, const void *rawin_dev, void *rawout_dev,
+                          hipEvent_t in_ready, hipEvent_t out_done) {
     int r = ensure_ready(e);
     if (r != BFHIP_OK) return r;
     const bool pipe = e->pipelined;
@@ -2367,6 +2433,8 @@ int bfhip_engine_block_dev(bfhip_engine *e, const void *rawin_dev, void *rawout_
     // of block t-2 (the MAC of t-1 reaches back only N = R-1 blocks).
     e->ls = pipe ? e->s_in : e->stream;
     if (pipe && e->blocks_done >= 2) HIPCHK(hipStreamWaitEvent(e->s_in, e->ev_mac[buf], 0));
+    // the caller's producer of rawin_dev (any stream): K1 must not start before it is done
+    if (in_ready) HIPCHK(hipStreamWaitEvent(e->ls, in_ready, 0));
     if ((r = record(e, 0)) != BFHIP_OK) return r;
     if ((r = do_inputs(e, rawin_dev)) != BFHIP_OK) return r;
     if ((r = record(e, 1)) != BFHIP_OK) return r;
@@ -2392,6 +2460,8 @@ int bfhip_engine_block_dev(bfhip_engine *e, const void *rawin_dev, void *rawout_
     if ((r = do_outputs(e, Zp, (size_t)e->n_out_padded * e->L, e->n_chunks, 0, e->n_ch[1], rawout_dev)) != BFHIP_OK) return r;
     if ((r = record(e, 5)) != BFHIP_OK) return r;
     if (pipe) HIPCHK(hipEventRecord(e->ev_out[buf], e->s_out));
+    // rawout_dev of THIS block is complete (and rawin_dev no longer needed) once this fires
+    if (out_done) HIPCHK(hipEventRecord(out_done, e->ls));
     e->ls = e->stream;
     advance(e);
     return BFHIP_OK;
@@ -2517,11 +2587,19 @@ int bfhip_engine_rt_wait(bfhip_engine *e, void *rawout, bfhip_overflow overflow[
     const int p = (int)(rt.waited & 1);
     HIPCHK(hipSetDevice(e->device));
     if ((rt.flags & BFHIP_RT_SPIN) && !(rt.flags & BFHIP_RT_OVERLAP)) {
-        // the tail kernel's last store is the sequence word: watch it from the CPU, fall back to
-        // the runtime after ~2 ms so that a device error cannot hang the caller
+        // the tail kernel's last store is the sequence word: watch it from the CPU; after 2 ms
+        // by the clock (checked every 256 polls) fall back to the runtime, so that a device
+        // error cannot hang the caller and a long block does not burn the core for its whole length
         volatile int *seq = rt.h_status[p] + 1;
-        long spin = 0;
-        for (; spin < 2000000 && *seq == 0; spin++) __builtin_ia32_pause();
+        struct timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (unsigned spin = 1; *seq == 0; spin++) {
+            __builtin_ia32_pause();
+            if ((spin & 255u) == 0) {
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > 2000000L) break;
+            }
+        }
         // seen: every store of the block (the tail kernel's copy-out included) is visible
         if (*seq == 0 || (rt.flags & BFHIP_RT_COPY_ENGINE)) HIPCHK(hipEventSynchronize(rt.done[p]));
     } else {

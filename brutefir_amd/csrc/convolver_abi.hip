@@ -364,6 +364,12 @@ void fatal(int code, const char *fmt, ...) {
 bool ensure_device() {
     if (!bfhip_conv_g.inited) { fatal(101, "convolver_init() has not been called."); return false; }
     // convolver_init() may have been called again (tests do): the sizes live in host_ops.cpp
+    if (G.rs != bfhip_conv_g.rs && !G.tw.empty()) {
+        // the twiddle tables are per precision
+        if (G.stream) (void)hipStreamSynchronize(G.stream);
+        for (auto &kv : G.tw) (void)hipFree(kv.second);
+        G.tw.clear();
+    }
     G.L = bfhip_conv_g.L; G.rs = bfhip_conv_g.rs; G.log2L = bfhip_conv_g.log2L; G.inited = true;
     const pid_t me = getpid();
     if (G.pid == me && G.stream) return true;

@@ -196,14 +196,27 @@ int bfhip_engine_set_fscale(bfhip_engine *e, int filter, int index, double scale
 int bfhip_engine_block(bfhip_engine *e, const void *rawin, void *rawout,
                        bfhip_overflow overflow[]);
 
-/* Device-resident raw buffers, asynchronous; rawin_dev must stay valid and rawout_dev is
-   complete only after bfhip_engine_sync().  For small crossbars (coefficient stream under
+/* Device-resident raw buffers, asynchronous (ordering contract: below).  For small crossbars (coefficient stream under
    ~100 us per block) the three kernels of a block are queued on three engine-owned streams so
    that the input FFT of the next block and the inverse FFT of the previous one run beside the
    MAC, the way the reference overlaps its input, filter and output processes; for large ones
    (the headline config) the plain sequence on one stream is faster.  BFHIP_OVERLAP=0/1 in the
    environment forces either. */
 int bfhip_engine_block_dev(bfhip_engine *e, const void *rawin_dev, void *rawout_dev);
+/* ORDERING CONTRACT of bfhip_engine_block_dev.  The engine launches on streams of its own (K1 of
+   a pipelined block even on a side stream that does NOT follow the stream given to
+   bfhip_engine_set_stream), so stream order alone protects nothing:
+     - rawin_dev must be COMPLETE on the device when the call is made (the producer has been
+       synchronised), and must not be rewritten before bfhip_engine_sync();
+     - rawout_dev may be read only after bfhip_engine_sync().
+   A caller that produces the input or consumes the output asynchronously uses the variant
+   below instead: in_ready_event (hipEvent_t, may be NULL) is an event the caller recorded behind
+   its producer of rawin_dev -- the input transform waits for it, nothing else does, so the
+   overlap of neighbouring blocks is kept; out_done_event (hipEvent_t, may be NULL) is recorded by
+   the engine behind the last kernel of THIS block: after it rawout_dev is complete and
+   rawin_dev may be reused. */
+int bfhip_engine_block_dev_ev(bfhip_engine *e, const void *rawin_dev, void *rawout_dev,
+                              void *in_ready_event, void *out_done_event);
 /* wait for the stream; returns accumulated status bits (and clears them) or an error */
 int bfhip_engine_sync(bfhip_engine *e);
 

@@ -247,3 +247,63 @@ assert got == "106", got
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "child fatal code 106" in r.stdout
+
+
+def test_block_dev_ev_orders_an_asynchronous_producer_and_consumer(hip):
+    """The ordering contract of bfhip_engine_block_dev (include/bfhip.h): with the pipelined
+    block (overlap forced on) K1 runs on a side stream that does not follow the caller's
+    stream.  A producer that fills the SAME input buffer on its own stream right before every
+    call, and a consumer that copies the output away on that stream right after, stay correct
+    when they hand the engine an `input ready` event and wait on its `output done` event -- no
+    host synchronisation anywhere in the loop.  Result must equal the plain synchronous engine
+    bit for bit."""
+    import torch
+    L, N, I, O = 2048, 4, 4, 4
+    dev = torch.device("cuda", 0)
+    ref_e, _ = cases.crossbar(hip.Engine, L, N, 4, I, O, "S24_4LE", "FLOAT_LE")
+    blocks = cases.raw_blocks(31, N + 6, L, I, "S24_4LE")
+    want = []
+    for blk in blocks:
+        st, raw = ref_e.block(blk)
+        assert st == 0
+        want.append(np.frombuffer(raw.tobytes(), np.float32).reshape(L, O).copy())
+
+    def build(overlap):
+        e = hip.Engine(L, N, 4, I, O)
+        e.set_interleaved(0, "S24_4LE")
+        e.set_interleaved(1, "FLOAT_LE")
+        for o in range(O):
+            for i in range(I):
+                h = cases.make_ir(np.random.default_rng(4321 + o * I + i), L * N, I)
+                e.add_filter(in_ch=[i], out_ch=[o], coeff=e.add_coeff(h))
+        e.set_overlap(overlap)
+        e.finalize()
+        return e
+
+    for overlap in (1, 0):
+        e = build(overlap)
+        side = torch.cuda.Stream()
+        pinned = [torch.from_numpy(b).pin_memory() for b in blocks]
+        rawin = torch.zeros(L, I, dtype=torch.int32, device=dev)          # ONE buffer, reused
+        rawout = torch.zeros(L, O, dtype=torch.float32, device=dev)
+        keep = [torch.zeros(L, O, dtype=torch.float32, device=dev) for _ in blocks]
+        big = torch.zeros(64 << 20, dtype=torch.uint8, device=dev)
+        ready = [torch.cuda.Event() for _ in blocks]
+        done = [torch.cuda.Event() for _ in blocks]
+        for ev in ready + done:
+            ev.record(side)                                               # creates the hipEvent_t handles
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            for k in range(len(blocks)):
+                if k > 0:
+                    side.wait_event(done[k - 1])                          # rawin may be rewritten now
+                big.fill_(k)                                              # keeps the producer stream busy
+                rawin.copy_(pinned[k], non_blocking=True)
+                ready[k].record(side)
+                e.block_dev_ev(rawin, rawout, ready[k].cuda_event, done[k].cuda_event)
+                side.wait_event(done[k])
+                keep[k].copy_(rawout, non_blocking=True)
+        torch.cuda.synchronize()
+        assert e.sync() == 0
+        for k in range(len(blocks)):
+            assert np.array_equal(keep[k].cpu().numpy(), want[k]), (overlap, k)
