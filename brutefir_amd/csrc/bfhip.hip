@@ -240,6 +240,17 @@ struct bfhip_engine {
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_mac[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
     int R = 0;                         // depth of the input rings
     void *d_Zp2 = nullptr;             // second partial-spectra buffer
+    // Deferred output (large crossbars on one stream): the inverse transforms of block t run in
+    // ONE launch with the forward transforms of block t+1 (io_wave_kernel) -- both are a handful
+    // of workgroups that would otherwise run back to back, each alone on the chip, in front of
+    // and behind the millisecond MAC.  The output of a block is therefore written during the
+    // NEXT bfhip_engine_block_dev call, or by bfhip_engine_sync (which flushes it).
+    bool defer_out = false;            // decided at finalize (BFHIP_DEFER=0/1 forces)
+    struct Pending {
+        bool on = false;
+        void *Zp = nullptr; size_t chunk_stride = 0; int n_chunks = 0;
+        void *rawout = nullptr; hipEvent_t out_done = nullptr;
+    } pend;
 
     // partition lengths above the LDS limit (bigfft.h): global scratch for [transform][L] complex
     bool big = false;
@@ -247,6 +258,9 @@ struct bfhip_engine {
     void *d_big[3] = {nullptr, nullptr, nullptr};   // zin, zmid, zout
     size_t big_cap = 0;            // transforms the scratch holds
     void *d_tw13 = nullptr;        // twiddle table of the 8192-point LDS transform
+    // K1 / K3 on the wave FFT (fft_wave.h: float32, L = 1024 .. 8192; BFHIP_FFT_WAVE=0 turns it off)
+    bool wave = false;
+    void *d_tww = nullptr;         // its twiddle table
     // K1/K3 in 256-thread workgroups (L = 8192): slow, but small enough to sit on a CU beside a MAC
     // workgroup, so that the side streams of the pipelined block do not displace MAC workgroups
     bool lowfoot = false;          // used for launches that go to the side streams only
@@ -436,6 +450,62 @@ void launch_fft_in(bfhip_engine *e, const uint8_t *raw, int slot, hipError_t *er
     hipLaunchKernelGGL(k, dim3(e->n_ch[0]), dim3(NT), lds, e->ls, raw, e->d_fmt[0],
                        (T *)e->d_prev, (c2<T> *)e->d_ring, (const c2<T> *)e->d_tw, e->R, slot,
                        (const BlockState *)e->bs_arg, ps_arg(e));
+    *err = hipGetLastError();
+}
+
+#define DISPATCH_WAVE(FN, ...)                             \
+    switch (e->log2L) {                                    \
+    case 10: FN<float, 10>(__VA_ARGS__); break;            \
+    case 11: FN<float, 11>(__VA_ARGS__); break;            \
+    case 12: FN<float, 12>(__VA_ARGS__); break;            \
+    case 13: FN<float, 13>(__VA_ARGS__); break;            \
+    default: break;                                        \
+    }
+
+template <typename T, int LOG2L>
+void launch_fft_in_wave(bfhip_engine *e, const uint8_t *raw, int slot, hipError_t *err) {
+    constexpr int NT = WaveGeo<LOG2L>::NT;
+    const size_t lds = lds_fft_bytes(LOG2L, sizeof(c2<T>));
+    auto k = fft_in_wave_kernel<T, LOG2L>;
+    *err = allow_lds(k, lds);
+    if (*err != hipSuccess) return;
+    hipLaunchKernelGGL(k, dim3(e->n_ch[0]), dim3(NT), lds, e->ls, raw, e->d_fmt[0],
+                       (T *)e->d_prev, (c2<T> *)e->d_ring, (const c2<T> *)e->d_tww, e->R, slot,
+                       (const BlockState *)e->bs_arg, ps_arg(e));
+    *err = hipGetLastError();
+}
+
+template <typename T, int LOG2L>
+void launch_ifft_out_wave(bfhip_engine *e, const void *Zp, size_t chunk_stride, int n_chunks,
+                          int first, int count, uint8_t *raw, hipError_t *err) {
+    constexpr int NT = WaveGeo<LOG2L>::NT;
+    const size_t lds = lds_fft_bytes(LOG2L, sizeof(c2<T>));
+    auto k = ifft_out_wave_kernel<T, LOG2L>;
+    *err = allow_lds(k, lds);
+    if (*err != hipSuccess) return;
+    hipLaunchKernelGGL(k, dim3(count), dim3(NT), lds, e->ls, (const c2<T> *)Zp, chunk_stride,
+                       n_chunks, first, e->d_fmt[1], e->d_over, (const unsigned char *)e->d_skip_quant,
+                       raw, e->d_timeout ? (T *)e->d_timeout + (size_t)first * e->L : (T *)nullptr,
+                       (const c2<T> *)e->d_tww, e->safety_limit, e->d_status);
+    *err = hipGetLastError();
+}
+
+// K3 of an earlier block (count channels from Zp) + K1 of the current block in one launch
+template <typename T, int LOG2L>
+void launch_io_wave(bfhip_engine *e, const void *Zp, size_t chunk_stride, int n_chunks, int first, int count,
+                    uint8_t *rawout, const uint8_t *rawin, int slot, hipError_t *err) {
+    constexpr int NT = WaveGeo<LOG2L>::NT;
+    const size_t lds = lds_fft_bytes(LOG2L, sizeof(c2<T>));
+    auto k = io_wave_kernel<T, LOG2L>;
+    *err = allow_lds(k, lds);
+    if (*err != hipSuccess) return;
+    hipLaunchKernelGGL(k, dim3(count + e->n_ch[0]), dim3(NT), lds, e->ls, count,
+                       (const c2<T> *)Zp, chunk_stride, n_chunks, first, e->d_fmt[1], e->d_over,
+                       (const unsigned char *)e->d_skip_quant, rawout,
+                       e->d_timeout ? (T *)e->d_timeout + (size_t)first * e->L : (T *)nullptr,
+                       e->safety_limit, e->d_status,
+                       rawin, e->d_fmt[0], (T *)e->d_prev, (c2<T> *)e->d_ring, e->R, slot,
+                       (const c2<T> *)e->d_tww, ps_arg(e), (const BlockState *)e->bs_arg);
     *err = hipGetLastError();
 }
 
@@ -1035,7 +1105,7 @@ int build_plan_t(bfhip_engine *e) {
         if (e->d_Zp2) (void)hipFree(e->d_Zp2);
         e->d_Zp2 = nullptr;
         HIPCHK(hipMalloc(&e->d_Zp, zb));
-        if (e->pipelined) HIPCHK(hipMalloc(&e->d_Zp2, zb));
+        if (e->pipelined || e->defer_out) HIPCHK(hipMalloc(&e->d_Zp2, zb));
         e->zp_bytes = zb;
     }
 
@@ -1131,10 +1201,29 @@ void timing_begin(bfhip_engine *e) {
 }
 
 int poll_coeff_changes(bfhip_engine *e);
+int do_outputs(bfhip_engine *e, const void *Zp, size_t chunk_stride, int n_chunks, int first,
+               int count, void *rawout_dev);
+
+// the inverse transforms of the block whose output is still owed (deferred output), on their own
+int flush_pending(bfhip_engine *e) {
+    if (!e->pend.on) return BFHIP_OK;
+    e->pend.on = false;
+    e->ls = e->stream;
+    const int r = do_outputs(e, e->pend.Zp, e->pend.chunk_stride, e->pend.n_chunks, 0, e->n_ch[1], e->pend.rawout);
+    if (r != BFHIP_OK) return r;
+    if (e->pend.out_done) HIPCHK(hipEventRecord(e->pend.out_done, e->stream));
+    e->pend.out_done = nullptr;
+    return BFHIP_OK;
+}
 
 int ensure_ready(bfhip_engine *e) {
     if (!e->finalized) return fail(BFHIP_ESTATE, "engine not finalized");
     HIPCHK(hipSetDevice(e->device));
+    if (e->plan_dirty && e->pend.on) {
+        // the owed output belongs to the old plan's geometry and buffers
+        const int r = flush_pending(e);
+        if (r != BFHIP_OK) return r;
+    }
     if (e->any_watched) {
         // one load of a shared counter per block; a partition another process rewrote since the
         // last block is re-uploaded now, before this block's plan / coefficient switch is applied
@@ -1301,6 +1390,7 @@ int do_inputs(bfhip_engine *e, const void *rawin_dev) {
     if (e->big) { int rr = big_reserve(e, (size_t)e->n_ch[0]); if (rr != BFHIP_OK) return rr; }
     if (e->big) DISPATCH_BIG(launch_fft_in_big, e, (const uint8_t *)rawin_dev, slot, &err);
     else if (e->lowfoot && e->ls != e->stream) DISPATCH_BIG(launch_fft_in_lo, e, (const uint8_t *)rawin_dev, slot, &err);
+    else if (e->wave) { DISPATCH_WAVE(launch_fft_in_wave, e, (const uint8_t *)rawin_dev, slot, &err) }
     else DISPATCH(launch_fft_in, e, (const uint8_t *)rawin_dev, slot, &err);
     if (err != hipSuccess) return fail(BFHIP_EHIP, "fft_in launch: %s", hipGetErrorString(err));
     return BFHIP_OK;
@@ -1349,6 +1439,10 @@ int do_outputs(bfhip_engine *e, const void *Zp, size_t chunk_stride, int n_chunk
     if (e->big) { int rr = big_reserve(e, (size_t)count); if (rr != BFHIP_OK) return rr; }
     if (e->big) DISPATCH_BIG(launch_ifft_out_big, e, Zp, chunk_stride, n_chunks, first, count, (uint8_t *)rawout_dev, &err);
     else if (e->lowfoot && e->ls != e->stream) DISPATCH_BIG(launch_ifft_out_lo, e, Zp, chunk_stride, n_chunks, first, count, (uint8_t *)rawout_dev, &err);
+    else if (e->wave) {
+        DISPATCH_WAVE(launch_ifft_out_wave, e, Zp, chunk_stride, n_chunks, first, count, (uint8_t *)rawout_dev, &err)
+        if (err == hipSuccess) { if (e->rs == 4) launch_dither<float>(e, first, count, (uint8_t *)rawout_dev, &err); }
+    }
     else DISPATCH(launch_ifft_out, e, Zp, chunk_stride, n_chunks, first, count, (uint8_t *)rawout_dev, &err);
     if (err != hipSuccess) return fail(BFHIP_EHIP, "ifft_out launch: %s", hipGetErrorString(err));
     { int rv = do_subdelay(e, 1, nullptr); if (rv != BFHIP_OK) return rv; }
@@ -1644,6 +1738,16 @@ bfhip_engine *bfhip_engine_create(int device, int length, int n_blocks, int real
         ok = ok && hipMalloc(&e->d_tw13, tw13.size()) == hipSuccess;
         ok = ok && hipMemcpy(e->d_tw13, tw13.data(), tw13.size(), hipMemcpyHostToDevice) == hipSuccess;
     }
+    // default from L = 4096 up: below that a workgroup of L/16 threads is one or two waves and the
+    // plain LDS transform with twice the threads has the shorter critical path (tools/fft_probe:
+    // L = 2048 5.6 vs 6.3 us, L = 1024 4.5 vs 5.4 us); BFHIP_FFT_WAVE=1 forces it on, =0 off
+    e->wave = wave_fft_ok(lg, realsize) && lg >= 12;
+    if (const char *env = getenv("BFHIP_FFT_WAVE")) e->wave = wave_fft_ok(lg, realsize) && atoi(env) != 0;
+    if (e->wave) {
+        const std::vector<unsigned char> tww = make_wave_twiddle_table(lg, realsize);
+        ok = ok && hipMalloc(&e->d_tww, tww.size()) == hipSuccess;
+        ok = ok && hipMemcpy(e->d_tww, tww.data(), tww.size(), hipMemcpyHostToDevice) == hipSuccess;
+    }
     ok = ok && hipMalloc((void **)&e->d_bad, sizeof(int)) == hipSuccess;
     ok = ok && hipMemset(e->d_bad, 0, sizeof(int)) == hipSuccess;
     if (!ok) {
@@ -1657,6 +1761,7 @@ bfhip_engine *bfhip_engine_create(int device, int length, int n_blocks, int real
 void bfhip_engine_destroy(bfhip_engine *e) {
     if (e == nullptr) return;
     (void)hipSetDevice(e->device);
+    e->pend.on = false;
     (void)sync_all(e);
     for (auto &c : e->coeffs) if (c.d_H) (void)hipFree(c.d_H);
     for (void *p : e->promoted) if (p) (void)hipFree(p);
@@ -1680,7 +1785,7 @@ void bfhip_engine_destroy(bfhip_engine *e) {
                     e->d_bad, e->d_Zp, e->d_entries, e->d_chunks, e->d_rawin, e->d_rawout, e->d_taps,
                     e->d_fring, e->d_Y, e->d_Yold, e->d_evalprev, e->d_jobs,
                     e->d_dither_ch, e->d_dither_state, e->d_dither_table, e->d_randmap, e->d_skip_quant, e->d_timeout,
-                    e->d_big[0], e->d_big[1], e->d_big[2], e->d_tw13, e->d_tw_lo,
+                    e->d_big[0], e->d_big[1], e->d_big[2], e->d_tw13, e->d_tw_lo, e->d_tww,
                     e->d_ps_flags, e->d_ps_live, e->d_ps_scale, e->d_ps_acc};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto ev : e->ev) (void)hipEventDestroy(ev);
@@ -2096,6 +2201,12 @@ int bfhip_engine_finalize(bfhip_engine *e) {
         for (int io = 0; io < 2; io++) for (int c : e->n_vpp[io]) if (c > 1) e->pipelined = false;   // one job table per side
         if (e->big) e->pipelined = false;          // one FFT scratch
         if (!e->pipelined) e->lowfoot = false;
+        // one stream and a MAC that fills the chip for a long time: fuse the output pass of a block
+        // with the input pass of the next one (deferred output).  Needs the plain 1:1 raw path.
+        bool plain = e->wave && !e->big && e->sdf_length <= 0 && e->dither_channels.empty();
+        for (int io = 0; io < 2; io++) for (int c : e->n_vpp[io]) if (c > 1) plain = false;
+        e->defer_out = !e->pipelined && plain && e->overlap_mode != 0 && bytes / 6.4e12 >= 100e-6;
+        if (const char *env = getenv("BFHIP_DEFER")) e->defer_out = atoi(env) != 0 && !e->pipelined && plain;
     }
     if (e->lowfoot) {
         const std::vector<unsigned char> twlo = make_twiddle_table(13, e->rs, LO_NT);
@@ -2344,6 +2455,7 @@ int bfhip_engine_set_fscale(bfhip_engine *e, int filter, int index, double scale
 int bfhip_engine_inputs_dev(bfhip_engine *e, const void *rawin_dev) {
     int r = ensure_ready(e);
     if (r != BFHIP_OK) return r;
+    if ((r = flush_pending(e)) != BFHIP_OK) return r;
     e->ls = e->stream;
     timing_begin(e);
     if ((r = record(e, 0)) != BFHIP_OK) return r;
@@ -2397,7 +2509,8 @@ int bfhip_engine_outputs_inputs_dev(bfhip_engine *e, const void *z_dev, int firs
     if ((r = record(e, 0)) != BFHIP_OK) return r;      // the fused launch is timed in the input slot
     hipError_t err = hipSuccess;
     const int slot = (int)(e->blockcounter % (unsigned int)e->R);
-    DISPATCH(launch_io, e, z_dev, first, count, (uint8_t *)rawout_dev, (const uint8_t *)rawin_dev, slot, &err);
+    if (e->wave) { DISPATCH_WAVE(launch_io_wave, e, z_dev, (size_t)0, 1, first, count, (uint8_t *)rawout_dev, (const uint8_t *)rawin_dev, slot, &err) }
+    else DISPATCH(launch_io, e, z_dev, first, count, (uint8_t *)rawout_dev, (const uint8_t *)rawin_dev, slot, &err);
     if (err != hipSuccess) return fail(BFHIP_EHIP, "io launch: %s", hipGetErrorString(err));
     return record(e, 1);
 }
@@ -2426,8 +2539,39 @@ static int block_dev_impl(bfhip_engine *e, const void *rawin_dev, void *rawout_d
     if (r != BFHIP_OK) return r;
     const bool pipe = e->pipelined;
     const int buf = (int)(e->blocks_done & 1);
-    void *Zp = (pipe && buf) ? e->d_Zp2 : e->d_Zp;
+    void *Zp = ((pipe || e->defer_out) && buf) ? e->d_Zp2 : e->d_Zp;
     timing_begin(e);
+
+    if (e->defer_out && !pipe) {
+        // [K3 of block t-1 | K1 of block t] in one launch, then the MAC of block t; K3 of block t is
+        // owed to the next call (or to sync).  Same kernels, same order per channel: same bits.
+        e->ls = e->stream;
+        if (in_ready) HIPCHK(hipStreamWaitEvent(e->stream, in_ready, 0));
+        if ((r = record(e, 0)) != BFHIP_OK) return r;
+        if (e->pend.on && e->pend.n_chunks <= 2) {
+            hipError_t err = hipSuccess;
+            const int slot = (int)(e->blockcounter % (unsigned int)e->R);
+            DISPATCH_WAVE(launch_io_wave, e, e->pend.Zp, e->pend.chunk_stride, e->pend.n_chunks, 0, e->n_ch[1],
+                          (uint8_t *)e->pend.rawout, (const uint8_t *)rawin_dev, slot, &err)
+            if (err != hipSuccess) return fail(BFHIP_EHIP, "io launch: %s", hipGetErrorString(err));
+            e->pend.on = false;
+            if (e->pend.out_done) HIPCHK(hipEventRecord(e->pend.out_done, e->stream));
+            e->pend.out_done = nullptr;
+        } else {
+            if ((r = flush_pending(e)) != BFHIP_OK) return r;
+            if ((r = do_inputs(e, rawin_dev)) != BFHIP_OK) return r;
+        }
+        if ((r = record(e, 1)) != BFHIP_OK) return r;
+        if ((r = do_levels(e)) != BFHIP_OK) return r;
+        if ((r = record(e, 2)) != BFHIP_OK) return r;
+        if ((r = do_mac(e, Zp)) != BFHIP_OK) return r;
+        if ((r = record(e, 3)) != BFHIP_OK) return r;
+        e->pend.on = true;
+        e->pend.Zp = Zp; e->pend.chunk_stride = (size_t)e->n_out_padded * e->L; e->pend.n_chunks = e->n_chunks;
+        e->pend.rawout = rawout_dev; e->pend.out_done = out_done;
+        advance(e);
+        return BFHIP_OK;
+    }
 
     // K1 on the input stream.  It overwrites the ring slot of block t-R, last read by the MAC
     // of block t-2 (the MAC of t-1 reaches back only N = R-1 blocks).
@@ -2470,6 +2614,7 @@ static int block_dev_impl(bfhip_engine *e, const void *rawin_dev, void *rawout_d
 int bfhip_engine_sync(bfhip_engine *e) {
     if (!e || !e->finalized) return fail(BFHIP_ESTATE, "engine not finalized");
     HIPCHK(hipSetDevice(e->device));
+    { int _r = flush_pending(e); if (_r != BFHIP_OK) return _r; }
     { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
     int st = 0;
     HIPCHK(hipMemcpy(&st, e->d_status, sizeof(int), hipMemcpyDeviceToHost));
@@ -2486,6 +2631,7 @@ int bfhip_engine_block(bfhip_engine *e, const void *rawin, void *rawout, bfhip_o
     if (overflow) HIPCHK(hipMemcpyAsync(e->d_over, overflow, e->n_ch[1] * sizeof(DevOverflow), hipMemcpyHostToDevice, sout));
     HIPCHK(hipMemcpyAsync(e->d_rawin, rawin, e->raw_bytes[0], hipMemcpyHostToDevice, sin));
     if ((r = bfhip_engine_block_dev(e, e->d_rawin, e->d_rawout)) != BFHIP_OK) return r;
+    if ((r = flush_pending(e)) != BFHIP_OK) return r;          // host buffers: this block's output is due now
     HIPCHK(hipMemcpyAsync(rawout, e->d_rawout, e->raw_bytes[1], hipMemcpyDeviceToHost, sout));
     if (overflow) HIPCHK(hipMemcpyAsync(overflow, e->d_over, e->n_ch[1] * sizeof(DevOverflow), hipMemcpyDeviceToHost, sout));
     return bfhip_engine_sync(e);
@@ -2494,6 +2640,7 @@ int bfhip_engine_block(bfhip_engine *e, const void *rawin, void *rawout, bfhip_o
 int bfhip_engine_rt_begin(bfhip_engine *e, int flags) {
     int r = ensure_ready(e);
     if (r != BFHIP_OK) return r;
+    if ((r = flush_pending(e)) != BFHIP_OK) return r;
     if (e->rt.on) return fail(BFHIP_ESTATE, "rt_begin: already in real-time mode");
     if ((r = sync_all(e)) != BFHIP_OK) return r;
     e->pipelined = false;                      // one stream: a period is needed back as soon as possible
@@ -2692,6 +2839,7 @@ int bfhip_engine_set_stream(bfhip_engine *e, void *hip_stream) {
 int bfhip_engine_get_overflow(bfhip_engine *e, int ch, bfhip_overflow *of) {
     if (!e || !e->finalized || ch < 0 || ch >= e->n_ch[1] || !of) return fail(BFHIP_EINVAL, "get_overflow: bad argument");
     HIPCHK(hipSetDevice(e->device));
+    { int _r = flush_pending(e); if (_r != BFHIP_OK) return _r; }
     { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
     HIPCHK(hipMemcpy(of, e->d_over + ch, sizeof(DevOverflow), hipMemcpyDeviceToHost));
     return BFHIP_OK;

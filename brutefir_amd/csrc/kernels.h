@@ -17,6 +17,7 @@
 #include <stdint.h>
 
 #include "fft_lds.h"
+#include "fft_wave.h"
 
 namespace bfhip {
 
@@ -344,6 +345,136 @@ fft_in_kernel(const uint8_t *__restrict__ raw, const DevFormat *__restrict__ fmt
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (bs) slot = (int)(bs->t % (unsigned int)R);
     fft_in_body<T, LOG2L, NTP>(blockIdx.x, smem, raw, fmt, prev, ring, tw, R, slot, ps);
+}
+
+// K1 on the wave FFT (fft_wave.h; float32, L = 1024 .. 8192, NT = L/16 threads): same statement as
+// fft_in_body -- window [previous L | new L], packed pairs, complex FFT, untangle into the ring
+// slot -- but the first radix pass runs on the registers the global loads landed in, and the last
+// two radix-8 passes are joined by wave-level exchanges.
+template <typename T, int LOG2L>
+__device__ __forceinline__ void
+fft_in_wave_body(int ch, unsigned char *smem, const uint8_t *__restrict__ raw, const DevFormat *__restrict__ fmt,
+                 T *__restrict__ prev, c2<T> *__restrict__ ring, const c2<T> *__restrict__ tw, int R, int slot,
+                 PowerSave ps) {
+    using G = WaveGeo<LOG2L>;
+    constexpr int L = G::L, NT = G::NT, QP = 8, QU = 8;
+    LdsArr<T> s{reinterpret_cast<c2<T> *>(smem)};
+    const int tid = threadIdx.x;
+    const DevFormat f = fmt[ch];
+    c2<T> *pv = reinterpret_cast<c2<T> *>(prev + (size_t)ch * L);
+    const uint8_t *base = f.alt ? f.alt : raw + f.byte_offset;
+    const size_t stride = (size_t)f.sample_spacing * f.bytes;
+
+    BF_PROBE(0);
+    // pair e of this thread is pair index tid + e*NT of its half of the window: the very elements
+    // its first-pass butterflies need (L/R0 = B0 * NT)
+    c2<T> old[QP], cur[QP];
+#pragma unroll
+    for (int e = 0; e < QP; e++) old[e] = pv[tid + e * NT];
+    const uintptr_t ba = (uintptr_t)base;
+    if (f.bytes == 4 && ((ba | stride) & 3) == 0) {
+        load_pairs_words<T, uint32_t, QP, NT, L / 2>(base, stride, f, tid, cur);
+    } else if (f.bytes == 2 && ((ba | stride) & 1) == 0) {
+        load_pairs_words<T, uint16_t, QP, NT, L / 2>(base, stride, f, tid, cur);
+    } else if (f.bytes == 8 && ((ba | stride) & 7) == 0) {
+        load_pairs_words<T, uint64_t, QP, NT, L / 2>(base, stride, f, tid, cur);
+    } else {
+#pragma unroll
+        for (int e = 0; e < QP; e++) {
+            const int n = tid + e * NT;
+            cur[e] = mk<T>(load_raw<T>(base + (size_t)(2 * n) * stride, f),
+                           load_raw<T>(base + (size_t)(2 * n + 1) * stride, f));
+        }
+    }
+    c2<T> *out = ring + ((size_t)ch * R + slot) * L;
+    if (ps.thr > 0.0) {                                   // uniform
+        __shared__ T ps_red[16];
+        const bool exact = ps.thr >= 1.0;
+        T m = (T)0;
+#pragma unroll
+        for (int e = 0; e < QP; e++) {
+            const T v4[4] = {old[e].x, old[e].y, cur[e].x, cur[e].y};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const T v = v4[q];
+                if (exact) {
+                    bool nz;
+                    if constexpr (sizeof(T) == 4) nz = __float_as_uint(v) != 0u;
+                    else nz = __double_as_longlong(v) != 0ll;
+                    if (nz) m = (T)1;
+                } else if (v < (T)0) { if (-v > m) m = -v; }
+                else { if (v > m) m = v; }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { const T o = __shfl_xor(m, off); m = o > m ? o : m; }
+        if ((tid & 63) == 0) ps_red[tid >> 6] = m;
+        __syncthreads();
+        m = ps_red[0];
+        for (int w = 1; w < NT / 64; w++) m = ps_red[w] > m ? ps_red[w] : m;
+        const bool silent = exact ? (m == (T)0) : !(ps.scale[ch] * (double)m >= ps.thr);
+        if (tid == 0) {
+            const int was = ps.flags[ch * R + slot], now = silent ? 1 : 0;
+            ps.flags[ch * R + slot] = now;
+            if (was != now) ps.live[ch] += was - now;
+        }
+        if (silent) {
+#pragma unroll
+            for (int e = 0; e < QP; e++) pv[tid + e * NT] = cur[e];
+            for (int k = tid; k < L; k += NT) out[k] = mk<T>((T)0, (T)0);
+            return;
+        }
+    }
+    WaveTw<T, LOG2L> twr;
+    twr.prefetch(tw);
+    c2<T> uw[QU];
+#pragma unroll
+    for (int i = 0; i < QU; i++) { const int k = 1 + tid + i * NT; uw[i] = tw[k <= L / 2 ? k : 0]; }
+    BF_PROBE(1);
+    // first pass straight from the loaded registers: butterfly b, input r = z[(tid + b*NT) + r*L/R0];
+    // the first R0/2 inputs come from the previous block, the others from the new one
+    c2<T> z[G::B0][G::R0];
+#pragma unroll
+    for (int b = 0; b < G::B0; b++) {
+#pragma unroll
+        for (int r = 0; r < G::R0; r++)
+            z[b][r] = r < G::R0 / 2 ? old[b + r * G::B0] : cur[b + (r - G::R0 / 2) * G::B0];
+    }
+#pragma unroll
+    for (int e = 0; e < QP; e++) pv[tid + e * NT] = cur[e];       // same thread read it above: no hazard
+    wave_p0_regs<T, LOG2L, false>(s, z);
+    BF_PROBE(2);
+    c2<T> x[2][8];
+    wave_p123<T, LOG2L, false>(s, twr, x);
+    BF_PROBE(8);
+    wave_store<T, LOG2L>(s, x);
+    BF_PROBE(10);
+
+    if (tid == 0) out[0] = mk<T>(s[0].x + s[0].y, s[0].x - s[0].y);
+    {
+        // bins k = 1 + tid + i*NT and L - k: NT is a multiple of 16, so both runs are one LDS
+        // address plus immediate offsets
+        const c2<T> *pk = lds_at(s, 1 + tid), *pl = lds_at(s, L - 1 - tid);
+#pragma unroll
+        for (int i = 0; i < QU; i++) {
+            const int k = 1 + tid + i * NT;
+            c2<T> xk, xlk;
+            untangle(pk[i * lds_stride(NT)], conj(pl[-i * lds_stride(NT)]), uw[i], xk, xlk);
+            out[k] = xk;
+            if (k != L - k) out[L - k] = xlk;
+        }
+    }
+    BF_PROBE(11);
+}
+
+template <typename T, int LOG2L>
+__global__ __launch_bounds__(WaveGeo<LOG2L>::NT) void
+fft_in_wave_kernel(const uint8_t *__restrict__ raw, const DevFormat *__restrict__ fmt, T *__restrict__ prev,
+                   c2<T> *__restrict__ ring, const c2<T> *__restrict__ tw, int R, int slot,
+                   const BlockState *__restrict__ bs, PowerSave ps) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (bs) slot = (int)(bs->t % (unsigned int)R);
+    fft_in_wave_body<T, LOG2L>(blockIdx.x, smem, raw, fmt, prev, ring, tw, R, slot, ps);
 }
 
 // ------------------------------------------------------------------ K7: taps -> coefficient partition
@@ -1190,6 +1321,217 @@ ifft_out_body(int zi /* index into Zp's channel axis */, unsigned char *smem,
         over[ch].largest = largest;
         if (st) atomicOr(status, st);
     }
+}
+
+// K3 on the wave FFT (fft_wave.h; float32, L = 1024 .. 8192): the statement of ifft_out_body with
+// the inverse transform's last two passes joined in-wave and the samples quantised straight from
+// the registers they end up in.
+template <typename T, int LOG2L>
+__device__ __forceinline__ void
+ifft_out_wave_body(int zi /* index into Zp's channel axis */, unsigned char *smem,
+              const c2<T> *__restrict__ Zp, size_t chunk_stride, int n_chunks,
+              int first_channel, const DevFormat *__restrict__ fmt,
+              DevOverflow *__restrict__ over, const unsigned char *__restrict__ skip_quant,
+              uint8_t *__restrict__ raw, T *__restrict__ timeout,
+              const c2<T> *__restrict__ tw, double safety_limit, int *__restrict__ status) {
+    using G = WaveGeo<LOG2L>;
+    constexpr int L = G::L, NT = G::NT, QU = 8;
+    LdsArr<T> s{reinterpret_cast<c2<T> *>(smem)};
+    __shared__ unsigned int red_n[16];
+    __shared__ int32_t red_i[16];
+    __shared__ double red_l[16];
+    const int tid = threadIdx.x;
+    const int ch = first_channel + zi;         // output channel
+    const c2<T> *z = Zp + (size_t)zi * L;
+
+    // Everything the kernel will need from global memory is requested up front, the spectra
+    // first (loads return in order: the sum and the LDS fill then only wait for those), the
+    // channel's format and overflow state last (they are needed after the transform).
+    c2<T> uw[QU], za[QU], zb[QU], ta[QU], tb[QU];
+    c2<T> z0 = mk<T>((T)0, (T)0), t0 = mk<T>((T)0, (T)0);
+    BF_PROBE(0);
+#pragma unroll
+    for (int i = 0; i < QU; i++) {
+        const int k = 1 + tid + i * NT;
+        if (k <= L / 2) { za[i] = z[k]; zb[i] = z[L - k]; }
+    }
+    if (tid == 0) z0 = z[0];
+    // the second chunk rides along only where the registers allow it (8 bins per thread in
+    // float64 at L = 8192 would spill)
+    constexpr bool PRELOAD2 = QU * sizeof(c2<T>) <= 64;
+    if (PRELOAD2 && n_chunks > 1) {
+        const c2<T> *zc = z + chunk_stride;
+#pragma unroll
+        for (int i = 0; i < QU; i++) {
+            const int k = 1 + tid + i * NT;
+            if (k <= L / 2) { ta[i] = zc[k]; tb[i] = zc[L - k]; }
+        }
+        if (tid == 0) t0 = zc[0];
+    }
+    WaveTw<T, LOG2L> twr;
+    twr.prefetch(tw);
+#pragma unroll
+    for (int i = 0; i < QU; i++) { const int k = 1 + tid + i * NT; uw[i] = tw[k <= L / 2 ? k : 0]; }
+    const DevFormat f = fmt[ch];
+    DevOverflow of = over[ch];
+    const bool quant = skip_quant == nullptr || !skip_quant[ch];
+    BF_PROBE(1);
+    // chunk partials add up in chunk order (deterministic)
+    if (PRELOAD2 && n_chunks > 1) {
+        z0 = z0 + t0;
+#pragma unroll
+        for (int i = 0; i < QU; i++) { za[i] = za[i] + ta[i]; zb[i] = zb[i] + tb[i]; }
+    }
+    for (int c = PRELOAD2 ? 2 : 1; c < n_chunks; c++) {
+        const c2<T> *zc = z + (size_t)c * chunk_stride;
+#pragma unroll
+        for (int i = 0; i < QU; i++) {
+            const int k = 1 + tid + i * NT;
+            if (k <= L / 2) { ta[i] = zc[k]; tb[i] = zc[L - k]; }
+        }
+        if (tid == 0) { t0 = zc[0]; z0 = z0 + t0; }
+#pragma unroll
+        for (int i = 0; i < QU; i++) { za[i] = za[i] + ta[i]; zb[i] = zb[i] + tb[i]; }
+    }
+    if (tid == 0) s[0] = mk<T>(z0.x + z0.y, z0.x - z0.y);
+    {
+        c2<T> *pk = lds_at(s, 1 + tid), *pl = lds_at(s, L - 1 - tid);     // k and L - k: see fft_in_wave_body
+#pragma unroll
+        for (int i = 0; i < QU; i++) {
+            const int k = 1 + tid + i * NT;
+            c2<T> zk, zlk;
+            tangle(za[i], conj(zb[i]), uw[i], zk, zlk);
+            pk[i * lds_stride(NT)] = zk;
+            if (k != L - k) pl[-i * lds_stride(NT)] = zlk;
+        }
+    }
+    BF_PROBE(2);
+    __syncthreads();
+    wave_p0_lds<T, LOG2L, true>(s);
+    BF_PROBE(4);
+    c2<T> xr[2][8];
+    wave_p123<T, LOG2L, true>(s, twr, xr);
+    BF_PROBE(8);
+    // xr[b][r] = z[wave_j(tid, b) + r * L/8]; the block's output samples are z[n], n < L/2: r < 4.
+    // They go to the quantiser from registers -- no LDS write, no barrier.
+
+    uint8_t *base = raw + f.byte_offset;
+    const size_t stride = (size_t)f.sample_spacing * f.bytes;
+    const int bits = f.sbytes << 3;
+    const int32_t imin = (int32_t)(-((uint64_t)1 << (bits - 1)));
+    const int32_t imax = (int32_t)(((uint64_t)1 << (bits - 1)) - 1);
+    const double rmin_i = (double)(T)imin, rmax_i = (double)(T)imax;
+    const T rmin_f = (T)(-of.max), rmax_f = (T)of.max;
+    unsigned int n_over = 0;
+    int32_t intlargest = of.intlargest;
+    double largest = of.largest;
+    int st = 0;
+
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const int n = wave_j<LOG2L>(tid, it >> 2) + (it & 3) * G::T8;
+        const c2<T> zz = xr[it >> 2][it & 3];
+        T xs[2] = {zz.x, zz.y};
+        if (timeout != nullptr) {
+            timeout[(size_t)zi * L + 2 * n] = xs[0];
+            timeout[(size_t)zi * L + 2 * n + 1] = xs[1];
+        }
+        if (!quant) continue;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const T x = xs[q];
+            uint8_t *p = base + (size_t)(2 * n + q) * stride;
+            uint8_t tb[8];
+            if (!isfinite(x)) { st |= 1; continue; }
+            if (safety_limit != 0.0 && ((double)x < -safety_limit * of.max || (double)x > safety_limit * of.max)) {
+                st |= 2; continue;
+            }
+            if (f.isfloat) {
+                if (x < (T)0) {
+                    if (x < rmin_f) n_over++;
+                    if ((double)x < -largest) largest = -(double)x;
+                } else {
+                    if (x > rmax_f) n_over++;
+                    if ((double)x > largest) largest = (double)x;
+                }
+                if (f.bytes == 4) {
+                    const uint32_t u = __float_as_uint((float)x);
+                    tb[0] = u & 0xff; tb[1] = (u >> 8) & 0xff; tb[2] = (u >> 16) & 0xff; tb[3] = u >> 24;
+                } else {
+                    const uint64_t u = (uint64_t)__double_as_longlong((double)x);
+#pragma unroll
+                    for (int i = 0; i < 8; i++) tb[i] = (u >> (8 * i)) & 0xff;
+                }
+            } else {
+                const int32_t v = real2int_no_dither((double)x, rmin_i, rmax_i, imin, imax,
+                                                     n_over, intlargest, largest);
+                const uint32_t u = (uint32_t)v;
+                tb[0] = u & 0xff; tb[1] = (u >> 8) & 0xff; tb[2] = (u >> 16) & 0xff; tb[3] = u >> 24;
+            }
+            store_raw_bytes(p, tb, f.bytes, f.swap);
+        }
+    }
+
+    BF_PROBE(10);
+    // workgroup reduction of the overflow bookkeeping (order independent: count, max, max)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        n_over += __shfl_down(n_over, off);
+        const int32_t oi = __shfl_down(intlargest, off);
+        intlargest = oi > intlargest ? oi : intlargest;
+        const double ol = __shfl_down(largest, off);
+        largest = ol > largest ? ol : largest;
+        st |= __shfl_down(st, off);
+    }
+    const int wave = tid >> 6, lane = tid & 63;
+    __shared__ int red_s[16];
+    if (lane == 0) { red_n[wave] = n_over; red_i[wave] = intlargest; red_l[wave] = largest; red_s[wave] = st; }
+    __syncthreads();
+    if (tid == 0 && quant) {
+        for (int w = 1; w < NT / 64; w++) {
+            n_over += red_n[w];
+            intlargest = red_i[w] > intlargest ? red_i[w] : intlargest;
+            largest = red_l[w] > largest ? red_l[w] : largest;
+            st |= red_s[w];
+        }
+        over[ch].n_overflows = of.n_overflows + n_over;
+        over[ch].intlargest = intlargest;
+        over[ch].largest = largest;
+        if (st) atomicOr(status, st);
+    }
+    BF_PROBE(11);
+}
+
+template <typename T, int LOG2L>
+__global__ __launch_bounds__(WaveGeo<LOG2L>::NT) void
+ifft_out_wave_kernel(const c2<T> *__restrict__ Zp, size_t chunk_stride, int n_chunks, int first_channel,
+                     const DevFormat *__restrict__ fmt, DevOverflow *__restrict__ over,
+                     const unsigned char *__restrict__ skip_quant, uint8_t *__restrict__ raw,
+                     T *__restrict__ timeout, const c2<T> *__restrict__ tw, double safety_limit,
+                     int *__restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ifft_out_wave_body<T, LOG2L>(blockIdx.x, smem, Zp, chunk_stride, n_chunks, first_channel, fmt, over,
+                                 skip_quant, raw, timeout, tw, safety_limit, status);
+}
+
+// K3 of one block and K1 of a later block in ONE launch on the wave FFT (see io_kernel)
+template <typename T, int LOG2L>
+__global__ __launch_bounds__(WaveGeo<LOG2L>::NT) void
+io_wave_kernel(int n_k3,
+               const c2<T> *__restrict__ Zp, size_t chunk_stride, int n_chunks, int first_channel,
+               const DevFormat *__restrict__ fmt_out, DevOverflow *__restrict__ over,
+               const unsigned char *__restrict__ skip_quant, uint8_t *__restrict__ rawout,
+               T *__restrict__ timeout, double safety_limit, int *__restrict__ status,
+               const uint8_t *__restrict__ rawin, const DevFormat *__restrict__ fmt_in, T *__restrict__ prev,
+               c2<T> *__restrict__ ring, int R, int slot, const c2<T> *__restrict__ tw, PowerSave ps,
+               const BlockState *__restrict__ bs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (bs) slot = (int)(bs->t % (unsigned int)R);
+    if ((int)blockIdx.x < n_k3)
+        ifft_out_wave_body<T, LOG2L>(blockIdx.x, smem, Zp, chunk_stride, n_chunks, first_channel, fmt_out, over,
+                                     skip_quant, rawout, timeout, tw, safety_limit, status);
+    else
+        fft_in_wave_body<T, LOG2L>((int)blockIdx.x - n_k3, smem, rawin, fmt_in, prev, ring, tw, R, slot, ps);
 }
 
 template <typename T, int LOG2L, int NTP = fft_threads<T>(LOG2L)>

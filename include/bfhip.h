@@ -208,7 +208,11 @@ int bfhip_engine_block_dev(bfhip_engine *e, const void *rawin_dev, void *rawout_
    bfhip_engine_set_stream), so stream order alone protects nothing:
      - rawin_dev must be COMPLETE on the device when the call is made (the producer has been
        synchronised), and must not be rewritten before bfhip_engine_sync();
-     - rawout_dev may be read only after bfhip_engine_sync().
+     - rawout_dev may be read only after bfhip_engine_sync(), and must stay valid until then or
+       until the NEXT block call has returned: for large crossbars on one stream the inverse
+       transforms of a block share one launch with the forward transforms of the next block
+       ("deferred output"; bfhip_engine_sync flushes what is owed; bfhip_engine_set_overlap(e, 0)
+       or BFHIP_DEFER=0 turn it off).
    A caller that produces the input or consumes the output asynchronously uses the variant
    below instead: in_ready_event (hipEvent_t, may be NULL) is an event the caller recorded behind
    its producer of rawin_dev -- the input transform waits for it, nothing else does, so the
@@ -288,7 +292,8 @@ int bfhip_engine_prewarm(bfhip_engine *e);
 int bfhip_engine_set_status_dev(bfhip_engine *e, int *status_dev);
 
 /* before finalize: -1 = decide from the plan (default), 0 = the three kernels of a block on one
-   stream, 1 = on three engine-owned streams (see bfhip_engine_block_dev) */
+   stream, strictly in order, output complete in stream order behind the call; 1 = on three
+   engine-owned streams (see bfhip_engine_block_dev) */
 int bfhip_engine_set_overlap(bfhip_engine *e, int mode);
 /* hipStream_t to run on (default: a stream owned by the engine) */
 int bfhip_engine_set_stream(bfhip_engine *e, void *hip_stream);

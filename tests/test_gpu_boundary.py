@@ -307,3 +307,95 @@ def test_block_dev_ev_orders_an_asynchronous_producer_and_consumer(hip):
         assert e.sync() == 0
         for k in range(len(blocks)):
             assert np.array_equal(keep[k].cpu().numpy(), want[k]), (overlap, k)
+
+
+def test_deferred_output_gives_the_same_samples(hip, monkeypatch):
+    """Large crossbars run [K3 of block t-1 | K1 of block t] as ONE launch (deferred output,
+    include/bfhip.h): the output of a block is written during the next call or by sync.  Forced
+    on here for a small crossbar; every block lands in a buffer of its own and is read after the
+    final sync; also with one shared output buffer and the `output done` event, and across a
+    run-time coefficient switch (plan rebuild with an output still owed)."""
+    import torch
+    L, N, I, O = 4096, 3, 3, 5
+    dev = torch.device("cuda", 0)
+    ref_e, irs = cases.crossbar(hip.Engine, L, N, 4, I, O, "S24_4LE", "S24_4LE")
+    blocks = cases.raw_blocks(12, N + 5, L, I, "S24_4LE")
+    extra = ref_e  # noqa: F841
+
+    def build():
+        e = hip.Engine(L, N, 4, I, O)
+        e.set_interleaved(0, "S24_4LE")
+        e.set_interleaved(1, "S24_4LE")
+        cs = {}
+        for o in range(O):
+            for i in range(I):
+                cs[(o, i)] = e.add_coeff(irs[(o, i)])
+                e.add_filter(in_ch=[i], out_ch=[o], coeff=cs[(o, i)])
+        return e, cs
+
+    # the reference run: synchronous block(), with a coefficient switch on filter 0 at block 4
+    monkeypatch.setenv("BFHIP_DEFER", "0")
+    plain, cs = build()
+    plain.finalize()
+    want = []
+    for k, blk in enumerate(blocks):
+        if k == 4:
+            plain.set_coeff(0, cs[(1, 1)])
+        st, raw = plain.block(blk)
+        assert st == 0
+        want.append(raw.view(np.int32).reshape(L, O).copy())
+    monkeypatch.setenv("BFHIP_DEFER", "1")
+    e, cs = build()
+    e.finalize()
+    srcs = [torch.from_numpy(b).to(dev) for b in blocks]
+    outs = [torch.zeros(L, O, dtype=torch.int32, device=dev) for _ in blocks]
+    torch.cuda.synchronize()
+    for k in range(len(blocks)):
+        if k == 4:
+            e.set_coeff(0, cs[(1, 1)])
+        e.block_dev(srcs[k], outs[k])
+    assert e.sync() == 0
+    for k in range(len(blocks)):
+        assert np.array_equal(outs[k].cpu().numpy(), want[k]), k
+    assert [e.overflow(c).astuple() for c in range(O)] == [plain.overflow(c).astuple() for c in range(O)]
+    # one shared output buffer: the `output done` event of block k fires when ITS samples are there
+    e2, _ = build()
+    e2.finalize()
+    shared = torch.zeros(L, O, dtype=torch.int32, device=dev)
+    keep = [torch.zeros(L, O, dtype=torch.int32, device=dev) for _ in blocks]
+    side = torch.cuda.Stream()
+    done = [torch.cuda.Event() for _ in blocks]
+    for ev in done:
+        ev.record(side)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for k in range(len(blocks)):
+            if k == 4:
+                e2.set_coeff(0, cs[(1, 1)])
+            e2.block_dev_ev(srcs[k], shared, None, done[k].cuda_event)
+            if k > 0:                                     # block k-1's output was written by this call
+                side.wait_event(done[k - 1])
+                keep[k - 1].copy_(shared, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(side)
+                ev.synchronize()                          # shared is free again before the next call
+        assert e2.sync() == 0
+        keep[-1].copy_(shared)
+    torch.cuda.synchronize()
+    for k in range(len(blocks)):
+        assert np.array_equal(keep[k].cpu().numpy(), want[k]), k
+
+
+@pytest.mark.parametrize("L", [1024, 2048])
+def test_wave_fft_forced_on_at_small_lengths(hip, monkeypatch, L):
+    """fft_wave.h is the default from L = 4096 up; BFHIP_FFT_WAVE=1 turns it on down to 1024 so
+    that every radix of its first pass (2, 4, 8, 16) is exercised against the oracle"""
+    monkeypatch.setenv("BFHIP_FFT_WAVE", "1")
+    ge, _ = cases.crossbar(hip.Engine, L, 3, 4, 3, 2, "S24_4LE", "FLOAT_LE")
+    monkeypatch.delenv("BFHIP_FFT_WAVE")
+    oe, _ = cases.crossbar(bo.Engine, L, 3, 4, 3, 2, "S24_4LE", "FLOAT_LE")
+    for blk in cases.raw_blocks(2, 7, L, 3, "S24_4LE"):
+        gs, g = ge.block(blk)
+        _, o = oe.block(blk)
+        assert gs == 0
+        assert cases.rel_rms(np.frombuffer(g.tobytes(), np.float32), np.frombuffer(o.tobytes(), np.float32)) <= 1e-5
