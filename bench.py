@@ -567,7 +567,12 @@ def main():
                                           " (overlapped with the next block)" if pipelined else ""))
                                       if world > 1
                                       else "single GPU",
-                       "status_bits": status if per_rank is None else max(p["status_bits"] for p in per_rank)},
+                       "status_bits": status if per_rank is None else max(p["status_bits"] for p in per_rank),
+                       "block_schedule": {0: "K1, MAC, K3 in order on one stream",
+                                          1: "pipelined: K1 of t+1 and K3 of t-1 on side streams beside the MAC of t",
+                                          2: "deferred output: [K3 of t-1 | K1 of t] in one launch, then the MAC of t"
+                                          }.get(eng.block_mode, "?") if world == 1 else "phase calls + fused [K3 | K1] launch",
+                       "fft": "wave-level (fft_wave.h)" if eng.uses_wave_fft else "LDS Stockham (fft_lds.h)"},
             "hbm_gbs_algorithmic": alg["block"] / (ms * 1e-3) / 1e9 if world == 1 else None,
         }
         if args.host_io:
@@ -587,6 +592,8 @@ def main():
             rf = mac_roofline(tm, alg["mac"])
             rf.update({"traffic": traffic, "traffic_stale": traffic_stale, "traffic_source_hash": traffic_src,
                        "launches": args.steps, "fft_in_ms": tm["fft_in_ms"], "ifft_out_ms": tm["ifft_out_ms"]})
+            if eng.block_mode == 2:
+                rf["fft_note"] = "fft_in_ms is the fused [K3 of t-1 | K1 of t] launch; there is no separate K3 launch"
             out["roofline"] = rf
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(wl)

@@ -122,6 +122,8 @@ def lib():
     L.bfhip_engine_blockcounter.restype = C.c_uint
     L.bfhip_engine_blockcounter.argtypes = [vp]
     L.bfhip_engine_ring_depth.argtypes = [vp]
+    L.bfhip_engine_block_mode.argtypes = [vp]
+    L.bfhip_engine_uses_wave_fft.argtypes = [vp]
     L.bfhip_engine_enable_timing.argtypes = [vp, ci]
     L.bfhip_engine_get_timing.argtypes = [vp, dp]
     L.bfhip_engine_algorithmic_bytes.argtypes = [vp, dp]
@@ -402,6 +404,15 @@ class Engine:
     @property
     def blockcounter(self):
         return lib().bfhip_engine_blockcounter(self.h)
+
+    @property
+    def block_mode(self):
+        """0 sequential, 1 pipelined (side streams), 2 deferred output (fused K3|K1 launch)"""
+        return lib().bfhip_engine_block_mode(self.h)
+
+    @property
+    def uses_wave_fft(self):
+        return bool(lib().bfhip_engine_uses_wave_fft(self.h))
 
     @property
     def ring_depth(self):

@@ -258,7 +258,7 @@ struct bfhip_engine {
     void *d_big[3] = {nullptr, nullptr, nullptr};   // zin, zmid, zout
     size_t big_cap = 0;            // transforms the scratch holds
     void *d_tw13 = nullptr;        // twiddle table of the 8192-point LDS transform
-    // K1 / K3 on the wave FFT (fft_wave.h: float32, L = 1024 .. 8192; BFHIP_FFT_WAVE=0 turns it off)
+    // K1 / K3 on the wave FFT (fft_wave.h: L = 1024 .. 8192, default from 4096 up; BFHIP_FFT_WAVE=0/1)
     bool wave = false;
     void *d_tww = nullptr;         // its twiddle table
     // K1/K3 in 256-thread workgroups (L = 8192): slow, but small enough to sit on a CU beside a MAC
@@ -453,14 +453,19 @@ void launch_fft_in(bfhip_engine *e, const uint8_t *raw, int slot, hipError_t *er
     *err = hipGetLastError();
 }
 
-#define DISPATCH_WAVE(FN, ...)                             \
+#define DISPATCH_WAVE_T(T, FN, ...)                        \
     switch (e->log2L) {                                    \
-    case 10: FN<float, 10>(__VA_ARGS__); break;            \
-    case 11: FN<float, 11>(__VA_ARGS__); break;            \
-    case 12: FN<float, 12>(__VA_ARGS__); break;            \
-    case 13: FN<float, 13>(__VA_ARGS__); break;            \
+    case 10: FN<T, 10>(__VA_ARGS__); break;                \
+    case 11: FN<T, 11>(__VA_ARGS__); break;                \
+    case 12: FN<T, 12>(__VA_ARGS__); break;                \
+    case 13: FN<T, 13>(__VA_ARGS__); break;                \
     default: break;                                        \
     }
+#define DISPATCH_WAVE(FN, ...)                                              \
+    do {                                                                    \
+        if (e->rs == 4) { DISPATCH_WAVE_T(float, FN, __VA_ARGS__) }         \
+        else { DISPATCH_WAVE_T(double, FN, __VA_ARGS__) }                   \
+    } while (0);
 
 template <typename T, int LOG2L>
 void launch_fft_in_wave(bfhip_engine *e, const uint8_t *raw, int slot, hipError_t *err) {
@@ -1441,7 +1446,10 @@ int do_outputs(bfhip_engine *e, const void *Zp, size_t chunk_stride, int n_chunk
     else if (e->lowfoot && e->ls != e->stream) DISPATCH_BIG(launch_ifft_out_lo, e, Zp, chunk_stride, n_chunks, first, count, (uint8_t *)rawout_dev, &err);
     else if (e->wave) {
         DISPATCH_WAVE(launch_ifft_out_wave, e, Zp, chunk_stride, n_chunks, first, count, (uint8_t *)rawout_dev, &err)
-        if (err == hipSuccess) { if (e->rs == 4) launch_dither<float>(e, first, count, (uint8_t *)rawout_dev, &err); }
+        if (err == hipSuccess) {
+            if (e->rs == 4) launch_dither<float>(e, first, count, (uint8_t *)rawout_dev, &err);
+            else launch_dither<double>(e, first, count, (uint8_t *)rawout_dev, &err);
+        }
     }
     else DISPATCH(launch_ifft_out, e, Zp, chunk_stride, n_chunks, first, count, (uint8_t *)rawout_dev, &err);
     if (err != hipSuccess) return fail(BFHIP_EHIP, "ifft_out launch: %s", hipGetErrorString(err));
@@ -2859,6 +2867,11 @@ int bfhip_engine_reset_overflow(bfhip_engine *e) {
 }
 
 unsigned int bfhip_engine_blockcounter(const bfhip_engine *e) { return e ? e->blockcounter : 0; }
+int bfhip_engine_block_mode(const bfhip_engine *e) {
+    if (!e || !e->finalized) return -1;
+    return e->pipelined ? BFHIP_MODE_PIPELINED : (e->defer_out ? BFHIP_MODE_DEFERRED : BFHIP_MODE_SEQUENTIAL);
+}
+int bfhip_engine_uses_wave_fft(const bfhip_engine *e) { return e && e->wave ? 1 : 0; }
 int bfhip_engine_ring_depth(const bfhip_engine *e) { return e ? e->R : 0; }
 
 int bfhip_engine_enable_timing(bfhip_engine *e, int on) {

@@ -133,7 +133,7 @@ template <int LOG2L> struct WaveGeo {
     static constexpr int NS2 = L / 64;        // sub-transform length entering P2
     static constexpr int NTW = 18;            // twiddle registers per thread: 3 passes x 2 butterflies x (w, w^2, w^4)
 };
-constexpr bool wave_fft_ok(int log2l, int realsize) { return realsize == 4 && log2l >= 10 && log2l <= 13; }
+constexpr bool wave_fft_ok(int log2l, int realsize) { return (realsize == 4 || realsize == 8) && log2l >= 10 && log2l <= 13; }
 
 // this thread's butterfly b of the lane-remapped passes P2 / P3: j = k + NS2 * q with the digit
 // q = lane bits 3..5 and k = the remaining bits of tid (+ NT/8 for the second butterfly)

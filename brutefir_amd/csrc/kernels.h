@@ -143,8 +143,11 @@ __device__ __forceinline__ void load_pairs_words(const uint8_t *__restrict__ bas
         const int n = tid + i * NT;
         w0[i] = 0; w1[i] = 0;
         if (HALF % NT == 0 || n < HALF) {
-            w0[i] = *reinterpret_cast<const W *>(base + (size_t)(2 * n) * stride);
-            w1[i] = *reinterpret_cast<const W *>(base + (size_t)(2 * n + 1) * stride);
+            // 32-bit byte offsets from the (uniform) channel base: scalar base + one VGPR offset per
+            // load instead of 64-bit multiplies (a block's raw extent is far below 4 GiB)
+            const uint32_t o = (uint32_t)(2 * n) * (uint32_t)stride;
+            w0[i] = *reinterpret_cast<const W *>(base + o);
+            w1[i] = *reinterpret_cast<const W *>(base + (o + (uint32_t)stride));
         }
     }
 #pragma unroll
@@ -347,7 +350,7 @@ fft_in_kernel(const uint8_t *__restrict__ raw, const DevFormat *__restrict__ fmt
     fft_in_body<T, LOG2L, NTP>(blockIdx.x, smem, raw, fmt, prev, ring, tw, R, slot, ps);
 }
 
-// K1 on the wave FFT (fft_wave.h; float32, L = 1024 .. 8192, NT = L/16 threads): same statement as
+// K1 on the wave FFT (fft_wave.h; L = 1024 .. 8192, NT = L/16 threads): same statement as
 // fft_in_body -- window [previous L | new L], packed pairs, complex FFT, untangle into the ring
 // slot -- but the first radix pass runs on the registers the global loads landed in, and the last
 // two radix-8 passes are joined by wave-level exchanges.
@@ -1323,7 +1326,38 @@ ifft_out_body(int zi /* index into Zp's channel axis */, unsigned char *smem,
     }
 }
 
-// K3 on the wave FFT (fft_wave.h; float32, L = 1024 .. 8192): the statement of ifft_out_body with
+// Wave-wide reductions for the overflow bookkeeping: four DPP steps (quad permutes, half-row and
+// row mirror: VALU only) leave every lane of a 16-lane row with the row's result, two shuffles
+// combine the four rows.  Every lane ends up with the wave's result.
+__device__ __forceinline__ int dpp_i32(int v, int ctrl_b1_4e_141_140) {
+    switch (ctrl_b1_4e_141_140) {
+    case 0: return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]
+    case 1: return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false);      // quad_perm [2,3,0,1]
+    case 2: return __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false);     // row_half_mirror
+    default: return __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false);    // row_mirror
+    }
+}
+template <typename OP> __device__ __forceinline__ int wave_all_i32(int v, OP op) {
+#pragma unroll
+    for (int st = 0; st < 4; st++) v = op(v, dpp_i32(v, st));
+    v = op(v, __shfl_xor(v, 16));
+    return op(v, __shfl_xor(v, 32));
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+    for (int st = 0; st < 4; st++) {
+        const long long q = __double_as_longlong(v);
+        const int lo = dpp_i32((int)(q & 0xffffffffll), st), hi = dpp_i32((int)(q >> 32), st);
+        const double o = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+        v = o > v ? o : v;
+    }
+    double o = __shfl_xor(v, 16);
+    v = o > v ? o : v;
+    o = __shfl_xor(v, 32);
+    return o > v ? o : v;
+}
+
+// K3 on the wave FFT (fft_wave.h; L = 1024 .. 8192): the statement of ifft_out_body with
 // the inverse transform's last two passes joined in-wave and the samples quantised straight from
 // the registers they end up in.
 template <typename T, int LOG2L>
@@ -1337,9 +1371,6 @@ ifft_out_wave_body(int zi /* index into Zp's channel axis */, unsigned char *sme
     using G = WaveGeo<LOG2L>;
     constexpr int L = G::L, NT = G::NT, QU = 8;
     LdsArr<T> s{reinterpret_cast<c2<T> *>(smem)};
-    __shared__ unsigned int red_n[16];
-    __shared__ int32_t red_i[16];
-    __shared__ double red_l[16];
     const int tid = threadIdx.x;
     const int ch = first_channel + zi;         // output channel
     const c2<T> *z = Zp + (size_t)zi * L;
@@ -1427,6 +1458,10 @@ ifft_out_wave_body(int zi /* index into Zp's channel axis */, unsigned char *sme
     double largest = of.largest;
     int st = 0;
 
+    // the common raw layout -- integer samples in naturally aligned 32-bit words (S24_4LE, S32_LE,
+    // their byte-swapped twins) -- is decided once for the channel: no byte assembly per sample
+    const bool word32 = quant && !f.isfloat && f.bytes == 4 && ((((uintptr_t)base) | stride) & 3) == 0;
+    const uint32_t stride32 = (uint32_t)stride;
 #pragma unroll
     for (int it = 0; it < 8; it++) {
         const int n = wave_j<LOG2L>(tid, it >> 2) + (it & 3) * G::T8;
@@ -1437,15 +1472,23 @@ ifft_out_wave_body(int zi /* index into Zp's channel axis */, unsigned char *sme
             timeout[(size_t)zi * L + 2 * n + 1] = xs[1];
         }
         if (!quant) continue;
+        const uint32_t o0 = (uint32_t)(2 * n) * stride32;
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             const T x = xs[q];
-            uint8_t *p = base + (size_t)(2 * n + q) * stride;
-            uint8_t tb[8];
+            uint8_t *p = base + (o0 + (q ? stride32 : 0u));
             if (!isfinite(x)) { st |= 1; continue; }
             if (safety_limit != 0.0 && ((double)x < -safety_limit * of.max || (double)x > safety_limit * of.max)) {
                 st |= 2; continue;
             }
+            if (word32) {
+                uint32_t u = (uint32_t)real2int_no_dither((double)x, rmin_i, rmax_i, imin, imax,
+                                                          n_over, intlargest, largest);
+                if (f.swap) u = __builtin_bswap32(u);
+                *reinterpret_cast<uint32_t *>(p) = u;
+                continue;
+            }
+            uint8_t tb[8];
             if (f.isfloat) {
                 if (x < (T)0) {
                     if (x < rmin_f) n_over++;
@@ -1473,30 +1516,18 @@ ifft_out_wave_body(int zi /* index into Zp's channel axis */, unsigned char *sme
     }
 
     BF_PROBE(10);
-    // workgroup reduction of the overflow bookkeeping (order independent: count, max, max)
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        n_over += __shfl_down(n_over, off);
-        const int32_t oi = __shfl_down(intlargest, off);
-        intlargest = oi > intlargest ? oi : intlargest;
-        const double ol = __shfl_down(largest, off);
-        largest = ol > largest ? ol : largest;
-        st |= __shfl_down(st, off);
-    }
-    const int wave = tid >> 6, lane = tid & 63;
-    __shared__ int red_s[16];
-    if (lane == 0) { red_n[wave] = n_over; red_i[wave] = intlargest; red_l[wave] = largest; red_s[wave] = st; }
-    __syncthreads();
-    if (tid == 0 && quant) {
-        for (int w = 1; w < NT / 64; w++) {
-            n_over += red_n[w];
-            intlargest = red_i[w] > intlargest ? red_i[w] : intlargest;
-            largest = red_l[w] > largest ? red_l[w] : largest;
-            st |= red_s[w];
-        }
-        over[ch].n_overflows = of.n_overflows + n_over;
-        over[ch].intlargest = intlargest;
-        over[ch].largest = largest;
+    // The overflow bookkeeping is order independent (a count, two maxima, status bits): every wave
+    // reduces its own share in registers and its first lane folds it into the channel's struct
+    // with atomics -- no LDS, no barrier behind the stores, and in the steady state (peaks already
+    // recorded, nothing clipped) no memory operation at all.
+    n_over = (unsigned int)wave_all_i32((int)n_over, [](int a, int b) { return a + b; });
+    intlargest = wave_all_i32(intlargest, [](int a, int b) { return a > b ? a : b; });
+    largest = wave_max_f64(largest);
+    st = wave_all_i32(st, [](int a, int b) { return a | b; });
+    if ((tid & 63) == 0 && quant) {
+        if (n_over) atomicAdd(&over[ch].n_overflows, n_over);
+        if (intlargest > of.intlargest) atomicMax(&over[ch].intlargest, intlargest);
+        if (largest > of.largest) atomicMax(&over[ch].largest, largest);
         if (st) atomicOr(status, st);
     }
     BF_PROBE(11);

@@ -301,6 +301,13 @@ int bfhip_engine_set_stream(bfhip_engine *e, void *hip_stream);
 int bfhip_engine_get_overflow(bfhip_engine *e, int out_channel, bfhip_overflow *of);
 int bfhip_engine_reset_overflow(bfhip_engine *e);     /* bf_reset_peak(), bfrun.c */
 unsigned int bfhip_engine_blockcounter(const bfhip_engine *e);
+/* how bfhip_engine_block_dev schedules the kernels of a block (decided at finalize): */
+#define BFHIP_MODE_SEQUENTIAL 0   /* K1, MAC, K3 of a block in order on one stream                 */
+#define BFHIP_MODE_PIPELINED  1   /* small MACs: K1 of t+1 and K3 of t-1 on side streams beside MAC t */
+#define BFHIP_MODE_DEFERRED   2   /* large MACs: [K3 of t-1 | K1 of t] in one launch, then MAC t     */
+int bfhip_engine_block_mode(const bfhip_engine *e);
+/* 1 if the input / output transforms run on the wave-level FFT (fft_wave.h) */
+int bfhip_engine_uses_wave_fft(const bfhip_engine *e);
 /* depth of the input spectrum rings (n_blocks, plus one spare slot when the block is pipelined) */
 int bfhip_engine_ring_depth(const bfhip_engine *e);
 
