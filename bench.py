@@ -41,6 +41,9 @@ WORKLOADS = {
     # what ONE rank of an N-GPU run of config C computes (inputs sharded, all outputs)
     "C2": (32, 64, 8192, 32, 4, "S24_4LE"), "C4": (16, 64, 8192, 32, 4, "S24_4LE"),
     "C8": (8, 64, 8192, 32, 4, "S24_4LE"),
+    # the headline crossbar with half / twice the partitions per filter (how much the per-filter
+    # start-up of the MAC's load pipeline costs: tools, not bench lines)
+    "C16": (64, 64, 8192, 16, 4, "S24_4LE"), "C64": (64, 64, 8192, 64, 4, "S24_4LE"),
     # a float64 crossbar of the headline's byte volume per filter (informative: the f64 MAC path)
     "F": (32, 32, 8192, 32, 8, "FLOAT64_LE"),
 }
@@ -389,13 +392,18 @@ def main():
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     taps = L * N
     tdt = torch.float32 if rs == 4 else torch.float64
-    for o in range(O):
-        for i in range(fi, fi + ci):
-            if args.workload in DIAGONAL and i != o:
-                continue
-            h = synth_ir_dev(torch, 4321 + o * I + i, taps, 1 if args.workload in DIAGONAL else I, device).to(tdt)
-            c = eng.add_coeff_dev(h, taps)
-            eng.add_filter(in_ch=[i - fi], out_ch=[o], coeff=c)
+    n_sets = sum(1 for o in range(O) for i in range(fi, fi + ci) if not (args.workload in DIAGONAL and i != o))
+    # what bfconf knows before it loads the first file: n_coeffs x n_blocks x cbufsize
+    eng.reserve_coeffs(float(n_sets) * N * 2 * L * rs)
+    pairs = [(o, i) for o in range(O) for i in range(fi, fi + ci)]
+    if os.environ.get("BFHIP_BENCH_ORDER") == "input-major":      # experiment: placement order of the sets
+        pairs = [(o, i) for i in range(fi, fi + ci) for o in range(O)]
+    for o, i in pairs:
+        if args.workload in DIAGONAL and i != o:
+            continue
+        h = synth_ir_dev(torch, 4321 + o * I + i, taps, 1 if args.workload in DIAGONAL else I, device).to(tdt)
+        c = eng.add_coeff_dev(h, taps)
+        eng.add_filter(in_ch=[i - fi], out_ch=[o], coeff=c)
     torch.cuda.synchronize()
     eng.finalize()
     alg = eng.algorithmic_bytes()

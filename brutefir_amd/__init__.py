@@ -90,6 +90,7 @@ def lib():
     for f in ("bfhip_engine_set_delay", "bfhip_engine_set_maxdelay", "bfhip_engine_set_mute"):
         getattr(L, f).argtypes = [vp, ci, ci, ci]
     L.bfhip_engine_enable_dither.argtypes = [vp, ip, ci, ci, ci]
+    L.bfhip_engine_reserve_coeffs.argtypes = [vp, cd]
     L.bfhip_engine_add_coeff.argtypes = [vp, vp, ci, cd, ci]
     L.bfhip_engine_add_coeff_dev.argtypes = [vp, vp, ci, cd, ci]
     L.bfhip_engine_update_coeff_block.argtypes = [vp, ci, ci, vp]
@@ -124,6 +125,7 @@ def lib():
     L.bfhip_engine_ring_depth.argtypes = [vp]
     L.bfhip_engine_block_mode.argtypes = [vp]
     L.bfhip_engine_uses_wave_fft.argtypes = [vp]
+    L.bfhip_engine_uses_stream_layout.argtypes = [vp]
     L.bfhip_engine_enable_timing.argtypes = [vp, ci]
     L.bfhip_engine_get_timing.argtypes = [vp, dp]
     L.bfhip_engine_algorithmic_bytes.argtypes = [vp, dp]
@@ -257,6 +259,9 @@ class Engine:
     def enable_dither(self, channels, sample_rate, max_size=0):
         _check(lib().bfhip_engine_enable_dither(self.h, _iarr(list(channels)), len(channels),
                                                 sample_rate, max_size))
+
+    def reserve_coeffs(self, total_bytes):
+        _check(lib().bfhip_engine_reserve_coeffs(self.h, float(total_bytes)))
 
     def add_coeff(self, taps, scale=1.0, n_blocks=0):
         taps = np.ascontiguousarray(taps, self.dt)
@@ -413,6 +418,10 @@ class Engine:
     @property
     def uses_wave_fft(self):
         return bool(lib().bfhip_engine_uses_wave_fft(self.h))
+
+    @property
+    def uses_stream_layout(self):
+        return bool(lib().bfhip_engine_uses_stream_layout(self.h))
 
     @property
     def ring_depth(self):

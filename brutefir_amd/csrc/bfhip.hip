@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -220,6 +221,26 @@ struct bfhip_engine {
     unsigned long long *d_ps_acc = nullptr;    // partition lengths above 8192: [2][n_in] running maxima
     double *d_ps_scale = nullptr;
     std::vector<Coeff> coeffs;
+    // Coefficient sets are carved out of a few large slabs instead of one hipMalloc each: the MAC
+    // streams all of them at once (config C: 4096 sets, 8 GiB), and what the address translation
+    // can keep hot depends on how large the physically contiguous pieces are -- thousands of
+    // separate 2 MiB allocations thrash the TLB (measured: the same crossbar with 16 / 32 / 64
+    // partitions per filter ran at 0.84 / 0.81 / 0.79 of peak).
+    struct Slab { void *base = nullptr; size_t cap = 0, used = 0; };
+    std::vector<Slab> slabs;
+    bool coeff_arena = true;               // BFHIP_COEFF_ARENA=0: one hipMalloc per set
+    unsigned int skew_state = 12345u;
+    // Stream-ordered copy of the coefficients for uniform crossbar plans (StreamLayout, kernels.h):
+    // every MAC workgroup reads one sequential slice.  Built / refreshed by build_plan.
+    int stream_wanted = 1;                 // BFHIP_COEFF_STREAM: 0 off, 1 from 64 MiB of coefficients up, 2 always
+    StreamLayout hstream = {nullptr, 0, 0, 0};
+    void *d_stream = nullptr;
+    size_t stream_cap = 0;
+    StreamWhere *d_where = nullptr;
+    int *d_which = nullptr;
+    size_t where_cap = 0;
+    std::vector<std::array<const void *, OG>> stream_keys;     // per flat entry: the sets laid out there
+    int stream_geom[5] = {0, 0, 0, 0, 0};                          // entries, E_c, P, n_tc, n_groups
     bool any_watched = false;
     unsigned long long watch_seq = 0;       // bfhip_coeff_dirty_sequence() at the last poll
     std::vector<Filter> filters;
@@ -390,6 +411,54 @@ int sync_all(bfhip_engine *e) {
     if (e->stream) HIPCHK(hipStreamSynchronize(e->stream));
     if (e->s_out) HIPCHK(hipStreamSynchronize(e->s_out));
     return BFHIP_OK;
+}
+
+// ---------------------------------------------------------------- coefficient memory
+
+void *coeff_alloc(bfhip_engine *e, size_t bytes) {
+    if (!e->coeff_arena) {
+        void *p = nullptr;
+        return hipMalloc(&p, bytes) == hipSuccess ? p : nullptr;
+    }
+    size_t need = (bytes + 65535) & ~(size_t)65535;                // sets start on 64 KiB
+    size_t skew = 0;
+    if (const char *env = getenv("BFHIP_COEFF_PAD_B")) {
+        if (env[0] == 'r') {
+            // pseudo-random start inside an extra 64 KiB (256-byte steps)
+            e->skew_state = e->skew_state * 1664525u + 1013904223u;
+            skew = (size_t)((e->skew_state >> 16) & 255u) * 256;
+            need = ((bytes + 255) & ~(size_t)255) + 65536;
+        } else need = (bytes + (size_t)atol(env) + 255) & ~(size_t)255;
+    }
+    if (!e->slabs.empty()) {
+        auto &sl = e->slabs.back();
+        if (sl.cap - sl.used >= need) { void *p = (unsigned char *)sl.base + sl.used + skew; sl.used += need; return p; }
+    }
+    // a first slab of 64 MiB keeps small engines small; whoever needs more gets 2 GiB pieces
+    // (config C, MAC alone, one box: one hipMalloc per set 0.83 of peak, 512 MiB slabs 0.86,
+    // >= 2 GiB slabs 0.883-0.886).  A host that knows the total calls bfhip_engine_reserve_coeffs.
+    size_t cap = e->slabs.empty() ? ((size_t)64 << 20) : ((size_t)2 << 30);
+    if (const char *env = getenv("BFHIP_COEFF_SLAB_MB")) cap = (size_t)std::max(1, atoi(env)) << 20;
+    cap = std::max(cap, need);
+    bfhip_engine::Slab sl;
+    while (hipMalloc(&sl.base, cap) != hipSuccess) {
+        (void)hipGetLastError();
+        if (cap <= need) return nullptr;
+        cap = std::max(need, cap / 2);
+    }
+    sl.cap = cap; sl.used = need;
+    e->slabs.push_back(sl);
+    return (unsigned char *)sl.base + skew;
+}
+
+// give back a set that was allocated last (error paths); anything else stays with its slab
+void coeff_release(bfhip_engine *e, void *p, size_t bytes) {
+    if (!p) return;
+    if (!e->coeff_arena) { (void)hipFree(p); return; }
+    if (e->slabs.empty()) return;
+    auto &sl = e->slabs.back();
+    const size_t need = (bytes + 65535) & ~(size_t)65535;
+    if (sl.used >= need && (unsigned char *)sl.base + sl.used - need == (unsigned char *)p) sl.used -= need;
 }
 
 // ---------------------------------------------------------------- template dispatch
@@ -623,7 +692,8 @@ void launch_mac(bfhip_engine *e, void *Zp, hipError_t *err) {
     hipLaunchKernelGGL((mac_xbar_kernel<T, NTFLAG, U>), dim3(grid), dim3(e->mac_threads), 0, e->ls,      \
                        (const MacEntry<T> *)e->d_entries, (const ChunkRange *)e->d_chunks,               \
                        (c2<T> *)Zp, e->L, e->n_out_padded, e->n_groups, e->n_chunks, n_tc,               \
-                       e->blockcounter, (int)age64, (const BlockState *)e->bs_arg)
+                       e->blockcounter, (int)age64, (const BlockState *)e->bs_arg,                       \
+                       (NTFLAG && U == 0) ? e->hstream : StreamLayout{nullptr, 0, 0, 0})
     if (!e->mac_nt) BFHIP_LAUNCH_MAC(false, 2);
     // the pipelined variant needs ~290 VGPRs: worth it for the pure crossbar, a loss of occupancy
     // for plans that (also) run the latency-bound per-term paths
@@ -819,6 +889,101 @@ int clamp_delay(const bfhip_engine *e, int d) {          // bfrun.c:1579-1584
 int cblocks_of(const bfhip_engine *e, int coeff, int delay) {   // bfrun.c:1585-1591
     if (coeff < 0 || e->coeffs[coeff].n_blocks > e->N - delay) return e->N - delay;
     return e->coeffs[coeff].n_blocks;
+}
+
+// (Re)build the stream-ordered coefficient copy for the plan just uploaded, if the plan is a
+// uniform crossbar: every entry OG coefficient terms of the same length, no split entries, every
+// chunk the same number of entries, no idle blocks in the grid.  Entries whose OG sets did not
+// change since the last build are left alone (scale changes rebuild the plan, not the data).
+template <typename T>
+int build_stream_layout(bfhip_engine *e, const std::vector<MacEntry<T>> &flat, const std::vector<ChunkRange> &chunks,
+                        int S, double bytes_H) {
+    e->hstream = StreamLayout{nullptr, 0, 0, 0};
+    if (!e->stream_wanted || !e->all_dense || flat.empty()) return BFHIP_OK;
+    if (e->stream_wanted == 1 && bytes_H < 64.0 * 1048576.0) return BFHIP_OK;      // cache resident anyway
+    const int n_tc = e->n_tiles * S;
+    if (n_tc % 8 != 0 || e->mac_threads != 256 || !e->mac_nt || e->mac_unroll != 0) return BFHIP_OK;
+    const int P = flat[0].maxP, E_c = chunks[0].end - chunks[0].begin;
+    for (auto &cr : chunks) if (cr.end - cr.begin != E_c) return BFHIP_OK;
+    for (auto &en : flat) if (en.dense != 1 || en.p0 != 0 || en.maxP != P) return BFHIP_OK;
+    if (E_c < 1 || P < 1) return BFHIP_OK;
+    const unsigned int chunk = 256u * 16u;
+    const unsigned long long entry_bytes = (unsigned long long)P * OG * chunk;
+    const unsigned long long slice = (unsigned long long)E_c * entry_bytes;
+    if (entry_bytes >= (1ull << 31) || slice >= (1ull << 32)) return BFHIP_OK;       // 32-bit offsets inside a slice
+    const unsigned long long grid = (unsigned long long)n_tc * e->n_groups;
+    const size_t total = (size_t)(grid * slice);
+    const int geom[5] = {(int)flat.size(), E_c, P, n_tc, e->n_groups};
+    const bool same_geom = e->d_stream != nullptr && memcmp(geom, e->stream_geom, sizeof(geom)) == 0;
+    if (!same_geom) {
+        if (total > e->stream_cap) {
+            if (e->d_stream) (void)hipFree(e->d_stream);
+            e->d_stream = nullptr; e->stream_cap = 0;
+            if (hipMalloc(&e->d_stream, total) != hipSuccess) {
+                (void)hipGetLastError();
+                return BFHIP_OK;                 // no room for the second copy: the set-major path still works
+            }
+            e->stream_cap = total;
+        }
+        e->stream_keys.clear();
+        memcpy(e->stream_geom, geom, sizeof(geom));
+    }
+    // which entries hold other sets than last time?
+    std::vector<int> changed;
+    std::vector<StreamWhere> where(flat.size());
+    e->stream_keys.resize(flat.size(), std::array<const void *, OG>{});
+    for (int g = 0; g < e->n_groups; g++) {
+        for (int c = 0; c < S; c++) {
+            const ChunkRange cr = chunks[(size_t)g * S + c];
+            for (int q = 0; q < E_c; q++) {
+                const int idx = cr.begin + q;
+                where[idx] = StreamWhere{g, c, q, 0};
+                std::array<const void *, OG> key;
+                for (int j = 0; j < OG; j++) key[j] = flat[idx].term[j].H;
+                if (key != e->stream_keys[idx]) { changed.push_back(idx); e->stream_keys[idx] = key; }
+            }
+        }
+    }
+    StreamLayout sl;
+    sl.base = (const unsigned char *)e->d_stream; sl.slice = slice; sl.entry_bytes = (unsigned int)entry_bytes; sl.chunk = chunk;
+    if (!changed.empty()) {
+        const size_t wb = where.size() * sizeof(StreamWhere), cb = changed.size() * sizeof(int);
+        if (wb + cb > e->where_cap) {
+            if (e->d_where) (void)hipFree(e->d_where);
+            e->d_where = nullptr;
+            HIPCHK(hipMalloc((void **)&e->d_where, wb + flat.size() * sizeof(int)));
+            e->where_cap = wb + flat.size() * sizeof(int);
+        }
+        e->d_which = (int *)((unsigned char *)e->d_where + wb);
+        HIPCHK(hipMemcpy(e->d_where, where.data(), wb, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(e->d_which, changed.data(), cb, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(stream_relayout_kernel<T>, dim3((unsigned)P, (unsigned)e->n_tiles, (unsigned)changed.size()), dim3(256), 0,
+                           e->stream, (const MacEntry<T> *)e->d_entries, (const StreamWhere *)e->d_where, (const int *)e->d_which,
+                           0, e->L, e->n_groups, S, sl);
+        HIPCHK(hipGetLastError());
+        { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
+    }
+    e->hstream = sl;
+    return BFHIP_OK;
+}
+
+// one partition of a coefficient set changed in place (update_coeff_block, refresh of a watched
+// set): bring the stream-ordered copy up to date
+template <typename T>
+int stream_refresh_block(bfhip_engine *e, const void *H, int block) {
+    if (e->hstream.base == nullptr || e->plan_dirty) return BFHIP_OK;       // a dirty plan is rebuilt (and compared) anyway
+    std::vector<int> hit;
+    for (size_t i = 0; i < e->stream_keys.size(); i++)
+        for (int j = 0; j < OG; j++) if (e->stream_keys[i][j] == H) { hit.push_back((int)i); break; }
+    if (hit.empty()) return BFHIP_OK;
+    const int P = e->stream_geom[2];
+    if (block >= P) return BFHIP_OK;
+    HIPCHK(hipMemcpy(e->d_which, hit.data(), hit.size() * sizeof(int), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(stream_relayout_kernel<T>, dim3(1u, (unsigned)e->n_tiles, (unsigned)hit.size()), dim3(256), 0, e->stream,
+                       (const MacEntry<T> *)e->d_entries, (const StreamWhere *)e->d_where, (const int *)e->d_which,
+                       block, e->L, e->n_groups, e->n_chunks, e->hstream);
+    HIPCHK(hipGetLastError());
+    return sync_all(e);
 }
 
 template <typename T>
@@ -1104,6 +1269,10 @@ int build_plan_t(bfhip_engine *e) {
     if (!flat.empty()) HIPCHK(hipMemcpy(e->d_entries, flat.data(), flat.size() * sizeof(MacEntry<T>), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->d_chunks, chunks.data(), cb, hipMemcpyHostToDevice));
     if (!blob.empty()) HIPCHK(hipMemcpy(e->d_jobs, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    {   // stream-ordered coefficient copy (StreamLayout) for uniform crossbar plans
+        const int r = build_stream_layout<T>(e, flat, chunks, S, bytes_H);
+        if (r != BFHIP_OK) return r;
+    }
     const size_t zb = (size_t)S * e->n_out_padded * L * sizeof(c2<T>);
     if (zb > e->zp_bytes) {
         if (e->d_Zp) (void)hipFree(e->d_Zp);
@@ -1749,6 +1918,8 @@ bfhip_engine *bfhip_engine_create(int device, int length, int n_blocks, int real
     // default from L = 4096 up: below that a workgroup of L/16 threads is one or two waves and the
     // plain LDS transform with twice the threads has the shorter critical path (tools/fft_probe:
     // L = 2048 5.6 vs 6.3 us, L = 1024 4.5 vs 5.4 us); BFHIP_FFT_WAVE=1 forces it on, =0 off
+    if (const char *env = getenv("BFHIP_COEFF_ARENA")) e->coeff_arena = atoi(env) != 0;
+    if (const char *env = getenv("BFHIP_COEFF_STREAM")) e->stream_wanted = atoi(env);
     e->wave = wave_fft_ok(lg, realsize) && lg >= 12;
     if (const char *env = getenv("BFHIP_FFT_WAVE")) e->wave = wave_fft_ok(lg, realsize) && atoi(env) != 0;
     if (e->wave) {
@@ -1771,7 +1942,8 @@ void bfhip_engine_destroy(bfhip_engine *e) {
     (void)hipSetDevice(e->device);
     e->pend.on = false;
     (void)sync_all(e);
-    for (auto &c : e->coeffs) if (c.d_H) (void)hipFree(c.d_H);
+    if (e->coeff_arena) { for (auto &sl : e->slabs) if (sl.base) (void)hipFree(sl.base); }
+    else { for (auto &c : e->coeffs) if (c.d_H) (void)hipFree(c.d_H); }
     for (void *p : e->promoted) if (p) (void)hipFree(p);
     for (int io = 0; io < 2; io++) for (auto &dl : e->vline[io]) if (dl.arena) (void)hipFree(dl.arena);
     if (e->d_incopy) (void)hipFree(e->d_incopy);
@@ -1794,7 +1966,7 @@ void bfhip_engine_destroy(bfhip_engine *e) {
                     e->d_fring, e->d_Y, e->d_Yold, e->d_evalprev, e->d_jobs,
                     e->d_dither_ch, e->d_dither_state, e->d_dither_table, e->d_randmap, e->d_skip_quant, e->d_timeout,
                     e->d_big[0], e->d_big[1], e->d_big[2], e->d_tw13, e->d_tw_lo, e->d_tww,
-                    e->d_ps_flags, e->d_ps_live, e->d_ps_scale, e->d_ps_acc};
+                    e->d_ps_flags, e->d_ps_live, e->d_ps_scale, e->d_ps_acc, e->d_stream, e->d_where};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto ev : e->ev) (void)hipEventDestroy(ev);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -1972,14 +2144,15 @@ static int add_coeff_common(bfhip_engine *e, const void *taps, bool on_device, i
     }
     Coeff c;
     c.n_blocks = n_blocks;
-    if (hipMalloc(&c.d_H, (size_t)n_blocks * L * e->csize()) != hipSuccess)
+    const size_t h_bytes = (size_t)n_blocks * L * e->csize();
+    if ((c.d_H = coeff_alloc(e, h_bytes)) == nullptr)
         return fail(BFHIP_ENOMEM, "out of device memory for coefficient set");
     hipError_t err = hipSuccess;
     if (e->big) {
-        { int rr = big_reserve(e, (size_t)n_blocks); if (rr != BFHIP_OK) { (void)hipFree(c.d_H); return rr; } }
+        { int rr = big_reserve(e, (size_t)n_blocks); if (rr != BFHIP_OK) { coeff_release(e, c.d_H, h_bytes); return rr; } }
         DISPATCH_BIG(launch_coeff_prep_big, e, src, n_taps, scale, c.d_H, n_blocks, &err);
     } else DISPATCH(launch_coeff_prep, e, src, n_taps, scale, c.d_H, n_blocks, &err);
-    if (err != hipSuccess) { (void)hipFree(c.d_H); return fail(BFHIP_EHIP, "coeff_prep launch: %s", hipGetErrorString(err)); }
+    if (err != hipSuccess) { coeff_release(e, c.d_H, h_bytes); return fail(BFHIP_EHIP, "coeff_prep launch: %s", hipGetErrorString(err)); }
     if (!on_device) {
         // host-taps path is synchronous, like convolver_coeffs2cbuf: report NaN/Inf now
         int bad = 0;
@@ -1987,12 +2160,29 @@ static int add_coeff_common(bfhip_engine *e, const void *taps, bool on_device, i
         HIPCHK(hipMemcpy(&bad, e->d_bad, sizeof(int), hipMemcpyDeviceToHost));
         if (bad) {
             HIPCHK(hipMemset(e->d_bad, 0, sizeof(int)));
-            (void)hipFree(c.d_H);
+            coeff_release(e, c.d_H, h_bytes);
             return fail(BFHIP_EINVAL, "NaN or Inf value among coefficients.");
         }
     }
     e->coeffs.push_back(c);
     return (int)e->coeffs.size() - 1;
+}
+
+int bfhip_engine_reserve_coeffs(bfhip_engine *e, double total_bytes) {
+    if (!e || total_bytes < 0) return fail(BFHIP_EINVAL, "reserve_coeffs: bad argument");
+    if (!e->coeff_arena || total_bytes == 0) return BFHIP_OK;
+    HIPCHK(hipSetDevice(e->device));
+    // every set is rounded up to 64 KiB: leave room for that
+    const size_t want = ((size_t)(total_bytes * 1.05) + ((size_t)1 << 20) + 65535) & ~(size_t)65535;
+    if (!e->slabs.empty() && e->slabs.back().cap - e->slabs.back().used >= want) return BFHIP_OK;
+    bfhip_engine::Slab sl;
+    if (hipMalloc(&sl.base, want) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(BFHIP_ENOMEM, "out of device memory reserving %.0f bytes of coefficient memory", total_bytes);
+    }
+    sl.cap = want; sl.used = 0;
+    e->slabs.push_back(sl);
+    return BFHIP_OK;
 }
 
 int bfhip_engine_add_coeff(bfhip_engine *e, const void *taps, int n_taps, double scale, int n_blocks) {
@@ -2026,7 +2216,7 @@ static int upload_processed_block(bfhip_engine *e, Coeff &c, int block, const vo
         hipLaunchKernelGGL(reorder_kernel<double>, grid, dim3(256), 0, e->stream, (const double *)e->d_taps, (c2<double> *)H, e->L, 1, (double *)nullptr);
     HIPCHK(hipGetLastError());
     { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
-    return BFHIP_OK;
+    return e->rs == 4 ? stream_refresh_block<float>(e, c.d_H, block) : stream_refresh_block<double>(e, c.d_H, block);
 }
 
 int bfhip_engine_add_coeff_processed_blocks(bfhip_engine *e, void *const cbufs[], int n_blocks, int watch) {
@@ -2036,13 +2226,14 @@ int bfhip_engine_add_coeff_processed_blocks(bfhip_engine *e, void *const cbufs[]
     HIPCHK(hipSetDevice(e->device));
     Coeff c;
     c.n_blocks = n_blocks;
-    if (hipMalloc(&c.d_H, (size_t)n_blocks * e->L * e->csize()) != hipSuccess)
+    const size_t h_bytes = (size_t)n_blocks * e->L * e->csize();
+    if ((c.d_H = coeff_alloc(e, h_bytes)) == nullptr)
         return fail(BFHIP_ENOMEM, "out of device memory for coefficient set");
     for (int b = 0; b < n_blocks; b++) {
         // generation first, data second: a notice that arrives in between is seen by the next poll
         const uint64_t gen = watch ? bfhip_dirty_generation(cbufs[b]) : 0;
         const int r = upload_processed_block(e, c, b, cbufs[b]);
-        if (r != BFHIP_OK) { (void)hipFree(c.d_H); return r; }
+        if (r != BFHIP_OK) { coeff_release(e, c.d_H, h_bytes); return r; }
         if (watch) { c.watch_src.push_back(cbufs[b]); c.watch_gen.push_back(gen); }
     }
     if (watch) {
@@ -2091,7 +2282,7 @@ int bfhip_engine_add_coeff_processed(bfhip_engine *e, const void *cbufs, int n_b
     HIPCHK(hipMemcpy(e->d_taps, cbufs, bytes, hipMemcpyHostToDevice));
     Coeff c;
     c.n_blocks = n_blocks;
-    if (hipMalloc(&c.d_H, (size_t)n_blocks * e->L * e->csize()) != hipSuccess)
+    if ((c.d_H = coeff_alloc(e, (size_t)n_blocks * e->L * e->csize())) == nullptr)
         return fail(BFHIP_ENOMEM, "out of device memory for coefficient set");
     const dim3 grid((e->L + 255) / 256, n_blocks);
     if (e->rs == 4)
@@ -2146,7 +2337,8 @@ int bfhip_engine_update_coeff_block(bfhip_engine *e, int coeff, int block, const
     } else DISPATCH(launch_coeff_prep, e, e->d_taps, e->L, 1.0, H, 1, &err);
     if (err != hipSuccess) return fail(BFHIP_EHIP, "coeff_prep launch: %s", hipGetErrorString(err));
     { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
-    return BFHIP_OK;
+    return e->rs == 4 ? stream_refresh_block<float>(e, e->coeffs[coeff].d_H, block)
+                      : stream_refresh_block<double>(e, e->coeffs[coeff].d_H, block);
 }
 
 int bfhip_engine_add_filter(bfhip_engine *e,
@@ -2872,6 +3064,7 @@ int bfhip_engine_block_mode(const bfhip_engine *e) {
     return e->pipelined ? BFHIP_MODE_PIPELINED : (e->defer_out ? BFHIP_MODE_DEFERRED : BFHIP_MODE_SEQUENTIAL);
 }
 int bfhip_engine_uses_wave_fft(const bfhip_engine *e) { return e && e->wave ? 1 : 0; }
+int bfhip_engine_uses_stream_layout(const bfhip_engine *e) { return e && e->hstream.base ? 1 : 0; }
 int bfhip_engine_ring_depth(const bfhip_engine *e) { return e ? e->R : 0; }
 
 int bfhip_engine_enable_timing(bfhip_engine *e, int on) {

@@ -64,6 +64,21 @@ template <typename T> struct MacEntry {
 
 struct ChunkRange { int begin, end; };
 
+// Stream-ordered copy of the coefficients of a uniform crossbar plan (every entry: OG coefficient
+// terms of the same length P, every chunk the same number of entries).  Workgroup `bid` of the MAC
+// grid owns the contiguous slice [bid * slice, (bid + 1) * slice): inside it, for each of its
+// entries q and partitions p, the OG tiles it multiplies with (one per output of its group), one
+// after the other:   base + bid*slice + ((q*P + p)*OG + j) * chunk + lane*16,   chunk = 256 * 16 B.
+// Every workgroup then reads ONE sequential stream front to back -- the access shape of a plain
+// read benchmark -- whatever order the host loaded its coefficient sets in and wherever their
+// allocations ended up (both move the set-major layout between 0.59 and 0.89 of peak).
+struct StreamLayout {
+    const unsigned char *base;      // null: coefficients are read set by set (MacTerm::H)
+    unsigned long long slice;       // bytes per workgroup
+    unsigned int entry_bytes;       // P * OG * chunk
+    unsigned int chunk;             // bytes of one tile of one set: blockDim.x * 16
+};
+
 // Per-block counters in device memory, for launch sequences replayed from a HIP graph (their
 // kernel arguments are frozen at capture time): t = blockcounter (bfrun.c:2034), age =
 // min(blocks processed + 1, N) (the procblocks guard, bfrun.c:1745).  Kernels take an optional
@@ -570,6 +585,34 @@ __global__ void reorder_kernel(const T *__restrict__ q, c2<T> *__restrict__ pack
     }
 }
 
+// set-major coefficient partitions -> the stream-ordered copy (StreamLayout).  One workgroup per
+// (partition, tile, entry); where[] names the chunk slot of every entry: (group, chunk, q).
+struct StreamWhere { int group, chunk, q, pad; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void
+stream_relayout_kernel(const MacEntry<T> *__restrict__ entries, const StreamWhere *__restrict__ where,
+                       const int *__restrict__ which, int p_first, int L, int n_groups, int n_chunks,
+                       StreamLayout sl) {
+    const int p = p_first + (int)blockIdx.x, tile = blockIdx.y;
+    const int e = which ? which[blockIdx.z] : (int)blockIdx.z;
+    const StreamWhere w = where[e];
+    // the MAC's own block decode, inverted: tc = tile * n_chunks + chunk, xcd = tc & 7
+    const int tc = tile * n_chunks + w.chunk;
+    const unsigned long long bid = (unsigned long long)((tc >> 3) * n_groups + w.group) * 8ull + (unsigned long long)(tc & 7);
+    const int P = (int)(sl.entry_bytes / ((unsigned int)OG * sl.chunk));
+    if (p >= P) return;
+    unsigned char *dst = const_cast<unsigned char *>(sl.base) + bid * sl.slice + (unsigned int)w.q * sl.entry_bytes +
+                         (unsigned int)p * ((unsigned int)OG * sl.chunk) + (unsigned int)threadIdx.x * 16u;
+    const size_t soff = ((size_t)p * L) * sizeof(c2<T>) + (size_t)tile * sl.chunk + (size_t)threadIdx.x * 16u;
+    if ((size_t)tile * sl.chunk + (size_t)threadIdx.x * 16u >= (size_t)L * sizeof(c2<T>)) return;
+#pragma unroll
+    for (int j = 0; j < OG; j++) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(entries[e].term[j].H) + soff);
+        *reinterpret_cast<uint4 *>(dst + (unsigned int)j * sl.chunk) = v;
+    }
+}
+
 // ------------------------------------------------------------------ K2: crossbar MAC
 
 // acc += x * h, complex, as four explicit fused multiply-adds in a fixed order.  Written out
@@ -609,7 +652,7 @@ template <typename T, bool NT, int UNROLL = 2>
 __global__ __launch_bounds__(256) void
 mac_xbar_kernel(const MacEntry<T> *__restrict__ entries, const ChunkRange *__restrict__ chunks,
                 c2<T> *__restrict__ Zp, int L, int n_out_padded, int n_groups, int n_chunks,
-                int n_tc, unsigned int t, int age, const BlockState *__restrict__ bs) {
+                int n_tc, unsigned int t, int age, const BlockState *__restrict__ bs, StreamLayout sl) {
     constexpr int V = 16 / sizeof(c2<T>);          // bins per lane: 2 (f32) / 1 (f64)
     if (bs) { t = bs->t; age = bs->age; }
     // XCD-aware decode (blocks b and b+8 share an XCD)
@@ -653,6 +696,16 @@ mac_xbar_kernel(const MacEntry<T> *__restrict__ entries, const ChunkRange *__res
 #pragma unroll
             for (int j = 0; j < OG; j++) { Hs[j] = E->term[j].H; sc[j] = E->term[j].scale; }
             constexpr int UR = UNROLL > 0 ? UNROLL : 2;
+            // where partition p of term j starts for this lane: Hs[j] + p * hstep + hlane
+            unsigned int hstep = (unsigned int)L * (unsigned int)sizeof(c2<T>);
+            unsigned int hlane = (unsigned int)k0 * (unsigned int)sizeof(c2<T>);
+            if (UNROLL == 0 && sl.base != nullptr) {
+                const unsigned char *wg = sl.base + (unsigned long long)bid * sl.slice + (unsigned int)(e - cr.begin) * sl.entry_bytes;
+#pragma unroll
+                for (int j = 0; j < OG; j++) Hs[j] = (const c2<T> *)(wg + (unsigned int)j * sl.chunk);
+                hstep = (unsigned int)OG * sl.chunk;
+                hlane = (unsigned int)threadIdx.x * 16u;
+            }
             if (mask != 0xffu) {
 #pragma unroll 2
                 for (int p = p0; p < maxP; p++) {
@@ -687,7 +740,7 @@ mac_xbar_kernel(const MacEntry<T> *__restrict__ entries, const ChunkRange *__res
                 auto issue = [&](Stage &st, int p) {
                     const unsigned int slot = (t - (unsigned int)p - (unsigned int)delay) % (unsigned int)R;
                     const unsigned int xoff = (slot * (unsigned int)L + (unsigned int)k0) * (unsigned int)sizeof(c2<T>);
-                    const unsigned int hoff = ((unsigned int)p * (unsigned int)L + (unsigned int)k0) * (unsigned int)sizeof(c2<T>);
+                    const unsigned int hoff = (unsigned int)p * hstep + hlane;
                     Load16<T, false>::get((const c2<T> *)((const char *)ring + xoff), st.x);
 #pragma unroll
                     for (int j = 0; j < OG; j++) Load16<T, NT>::get((const c2<T> *)((const char *)Hs[j] + hoff), st.h[j]);

@@ -127,6 +127,15 @@ int bfhip_engine_set_powersave(bfhip_engine *e, double analog_powersave);
 int bfhip_engine_enable_dither(bfhip_engine *e, const int out_channels[], int n,
                                int sample_rate, int max_size);
 
+/* Optional, before the first add_coeff*: the total size of all coefficient sets to come, in bytes
+   of device memory (sum over sets of n_blocks * 2L * realsize -- what bfconf knows as
+   n_coeffs x n_blocks x convolver_cbufsize()).  The sets are then carved out of ONE allocation.
+   The MAC streams every set of the filter network in every block; how well that runs depends on
+   how large the physically contiguous pieces behind them are (address translation): one slab is
+   worth ~6 % at the headline configuration over one allocation per set.  Without the call the
+   engine allocates 2 GiB slabs as it goes, which gets most of it.  (`double`: the figure easily
+   exceeds 2^31.) */
+int bfhip_engine_reserve_coeffs(bfhip_engine *e, double total_bytes);
 /* load_coeff() for a time-domain coefficient set (bfconf.c:1867-2030): split into
    n_blocks partitions of L taps (n_blocks <= 0: as many as the taps need), each through
    convolver_coeffs2cbuf (fftw_convolver.c:526-573).  taps are `realsize`-wide reals in
@@ -308,6 +317,9 @@ unsigned int bfhip_engine_blockcounter(const bfhip_engine *e);
 int bfhip_engine_block_mode(const bfhip_engine *e);
 /* 1 if the input / output transforms run on the wave-level FFT (fft_wave.h) */
 int bfhip_engine_uses_wave_fft(const bfhip_engine *e);
+/* 1 if the MAC reads a stream-ordered copy of the coefficients (uniform crossbar plans: every
+   workgroup one sequential slice; costs a second copy of the coefficient memory) */
+int bfhip_engine_uses_stream_layout(const bfhip_engine *e);
 /* depth of the input spectrum rings (n_blocks, plus one spare slot when the block is pipelined) */
 int bfhip_engine_ring_depth(const bfhip_engine *e);
 

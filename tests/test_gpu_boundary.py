@@ -401,3 +401,82 @@ def test_wave_fft_forced_on_at_small_lengths(hip, monkeypatch, L):
         _, o = oe.block(blk)
         assert gs == 0
         assert cases.rel_rms(np.frombuffer(g.tobytes(), np.float32), np.frombuffer(o.tobytes(), np.float32)) <= 1e-5
+
+
+@pytest.mark.parametrize("rs", [4, 8])
+def test_stream_ordered_coefficients_follow_runtime_changes(hip, cv, monkeypatch, rs):
+    """Uniform crossbars are multiplied from a stream-ordered COPY of the coefficients (every MAC
+    workgroup one sequential slice, kernels.h StreamLayout).  The copy has to follow everything
+    that changes coefficients at run time: a filter switching to another set (plan rebuild, only
+    the touched entries are laid out again), bfhip_engine_update_coeff_block, and a watched
+    partition rewritten by another process.  Forced on for a small crossbar; the oracle is the
+    checker, and an engine without the copy must give the same bits."""
+    dt = np.float32 if rs == 4 else np.float64
+    L, N, I, O = 1024, 4, 8, 8
+    tol = 1e-5 if rs == 4 else 1e-12
+    assert cv.convolver_init(None, L, rs) == 1
+    rng = np.random.default_rng(3)
+    irs = {(o, i): cases.make_ir(np.random.default_rng(50 + o * I + i), L * N, I).astype(dt) for o in range(O) for i in range(I)}
+    alt = cases.make_ir(rng, L * N, I).astype(dt)
+    shm = mmap.mmap(-1, N * 2 * L * rs)
+    base = np.frombuffer(shm, dt)
+    addr = [base[b * 2 * L:].ctypes.data for b in range(N)]
+
+    def build(mod, stream):
+        monkeypatch.setenv("BFHIP_COEFF_STREAM", stream)
+        monkeypatch.setenv("BFHIP_MAC_TARGET_WGS", "8")      # 2 bin tiles x 4 chunks of 2 inputs: a uniform grid
+        e = mod.Engine(L, N, rs, I, O)
+        e.set_interleaved(0, "S24_4LE")
+        e.set_interleaved(1, "FLOAT_LE" if rs == 4 else "FLOAT64_LE")
+        cs = {}
+        for (o, i), h in irs.items():
+            if mod is hip and (o, i) == (0, 0):
+                for b in range(N):
+                    _render(cv, h[b * L:(b + 1) * L], L, rs, addr[b])
+                cs[(o, i)] = e.add_coeff_processed_blocks(addr, watch=True)     # lives in "shared memory"
+            else:
+                cs[(o, i)] = e.add_coeff(h)
+            e.add_filter(in_ch=[i], out_ch=[o], coeff=cs[(o, i)])
+        c_alt = e.add_coeff(alt)
+        if hasattr(e, "finalize"):
+            e.finalize()
+        return e, cs, c_alt
+
+    se, scs, salt = build(hip, "2")
+    pe, pcs, palt = build(hip, "0")
+    assert se.uses_stream_layout and not pe.uses_stream_layout
+    oe, ocs, oalt = build(bo, "0")
+    new_part = cases.make_ir(rng, L, I).astype(dt)
+    h00 = irs[(0, 0)].copy()
+    h00[L:2 * L] = new_part
+    o_h00 = oe.add_coeff(h00)
+    new_blk = cases.make_ir(rng, L, I).astype(dt)
+    h35 = irs[(3, 5)].copy()
+    h35[2 * L:3 * L] = new_blk
+    o_h35 = oe.add_coeff(h35)
+    f35 = 3 * I + 5
+    blocks = cases.raw_blocks(4, 3 * N + 4, L, I, "S24_4LE")
+    for k, blk in enumerate(blocks):
+        if k == N + 1:                               # filter (out 2, in 6) switches to another set
+            f = 2 * I + 6
+            for e, c in ((se, salt), (pe, palt), (oe, oalt)):
+                e.set_coeff(f, c)
+        if k == N + 3:                               # one partition of set (3, 5) replaced in place
+            se.update_coeff_block(scs[(3, 5)], 2, new_blk)
+            pe.update_coeff_block(pcs[(3, 5)], 2, new_blk)
+            oe.set_coeff(f35, o_h35)
+        if k == 2 * N + 2:                           # "another process" rewrites partition 1 of the watched set
+            pid = os.fork()
+            if pid == 0:
+                try:
+                    cv.convolver_runtime_coeffs2cbuf(p(np.ascontiguousarray(new_part)), C.c_void_p(addr[1]))
+                finally:
+                    os._exit(0)
+            assert os.waitpid(pid, 0)[1] == 0
+            oe.set_coeff(0, o_h00)
+        s1, g = se.block(blk)
+        s2, q = pe.block(blk)
+        _, w = oe.block(blk)
+        assert s1 == 0 and s2 == 0
+        assert np.array_equal(g, q), k               # same arithmetic, different memory layout
+        assert cases.rel_rms(np.frombuffer(g.tobytes(), dt), np.frombuffer(w.tobytes(), dt)) <= tol, k

@@ -142,6 +142,15 @@ bfhip_setup(int n_filters,
     /* Coefficient sets exactly as bfconf_init() prepared them (convolver_coeffs2cbuf in the
        parent, or "processed" / shared-memory data): one cbuf per block.  Sets in shared
        memory may be rewritten by a module process at run time (bflogic_eq): watched. */
+    {
+        double total = 0;
+        for (c = 0; c < bfconf->n_coeffs; c++) {
+            total += (double)bfconf->coeffs[c].n_blocks * (double)convolver_cbufsize();
+        }
+        if (bfhip_engine_reserve_coeffs(bfhip_eng, total) < 0) {
+            bfhip_die("reserve_coeffs");
+        }
+    }
     for (c = 0; c < bfconf->n_coeffs; c++) {
         if (bfhip_engine_add_coeff_processed_blocks(bfhip_eng,
                                                     bfconf->coeffs_data[c],

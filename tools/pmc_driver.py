@@ -30,6 +30,7 @@ def main():
     rng = np.random.default_rng(5)
     h = rng.standard_normal(L * N) * np.exp(-np.arange(L * N) / (L * N / 6.0))
     h = (h / (np.abs(h).sum() * I)).astype(np.float32 if rs == 4 else np.float64)
+    e.reserve_coeffs(float(I * O) * N * 2 * L * rs)
     for o in range(O):
         for i in range(I):
             e.add_filter(in_ch=[i], out_ch=[o], coeff=e.add_coeff(h))
