@@ -120,13 +120,19 @@ def cpu_baseline(wl, seconds=10.0):
     import bforacle as bo
     bo.lib()                                          # build once, before the workers race for it
     I, O, L, N, rs, fmt = wl
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    # every core this process may run on (no cap): the reference's default is one filter process
-    # per core too (bfconf.c:2227-2318 spreads the filters over n_processes)
-    cores = max(1, cores)
+    # every core this process may really use -- the affinity mask cut down to the cgroup's CPU
+    # quota, which is what a container on a shared host actually gets -- and no artificial cap:
+    # the reference's default is one filter process per core too (bfconf.c:2227-2318)
+    cores, cores_note = usable_cores()
+    try:                                              # ... and that the workers' engines fit in memory
+        avail = [int(ln.split()[1]) * 1024 for ln in open("/proc/meminfo") if ln.startswith("MemAvailable")][0]
+        per_worker = min(O, 2) * I * N * 2 * L * rs * 1.5 + (256 << 20)
+        fit = max(1, int(0.5 * avail / per_worker))
+        if fit < cores:
+            cores_note += ", %d workers fit in half of the available memory" % fit
+            cores = fit
+    except (OSError, IndexError, ValueError):
+        pass
     single = _cpu_worker((wl, 0, seconds / 2))
     agg, per = single[0], [single]
     if cores > 1:
@@ -149,7 +155,8 @@ def cpu_baseline(wl, seconds=10.0):
             cores = 1                                 # report what was measured
     ref_loop = reference_hot_loop(bo, L, rs, I, N, cores=cores)
     return {"value": agg, "unit": "samples/s", "cores": cores, "kind": "port",
-            "nproc": os.cpu_count(), "cpu_model": cpu_model(), "compiler_flags": "gcc -O2 (oracle), gcc -O2 -msse -msse2 (oracle/_ref)",
+            "nproc": os.cpu_count(), "cores_note": cores_note, "cpu_model": cpu_model(),
+            "compiler_flags": "gcc -O2 (oracle), gcc -O2 -msse -msse2 (oracle/_ref)",
             "single_core_value": single[0],
             "reference_hot_loop": ref_loop,
             "sample": "per core: %d of %d outputs x %d inputs x %d partitions of %d taps, %d-%d steady-state "
@@ -237,6 +244,29 @@ def source_hash():
         h.update(rel.encode())
         h.update(open(os.path.join(ROOT, rel), "rb").read())
     return h.hexdigest()[:16]
+
+
+def usable_cores():
+    """(worker processes to start, how that number came about)"""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except AttributeError:
+        aff = os.cpu_count() or 1
+    quota = None
+    try:                                              # cgroup v2: "<quota> <period>" or "max <period>"
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(float(q) / float(per) + 0.5))
+    except (OSError, ValueError):
+        try:                                          # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                quota = max(1, int(q / per + 0.5))
+        except (OSError, ValueError):
+            pass
+    n = max(1, min(aff, quota) if quota else aff)
+    return n, "affinity mask %d, cgroup cpu quota %s, os.cpu_count %s" % (aff, quota if quota else "none", os.cpu_count())
 
 
 def cpu_model():
