@@ -2406,7 +2406,9 @@ int bfhip_engine_finalize(bfhip_engine *e) {
         bool plain = e->wave && !e->big && e->sdf_length <= 0 && e->dither_channels.empty();
         for (int io = 0; io < 2; io++) for (int c : e->n_vpp[io]) if (c > 1) plain = false;
         e->defer_out = !e->pipelined && plain && e->overlap_mode != 0 && bytes / 6.4e12 >= 100e-6;
-        if (const char *env = getenv("BFHIP_DEFER")) e->defer_out = atoi(env) != 0 && !e->pipelined && plain;
+        // (an explicit bfhip_engine_set_overlap(e, 0) -- "strictly in order" -- beats the environment:
+        // the non-uniform convolver relies on it for its segment engines)
+        if (const char *env = getenv("BFHIP_DEFER")) e->defer_out = atoi(env) != 0 && !e->pipelined && plain && e->overlap_mode != 0;
     }
     if (e->lowfoot) {
         const std::vector<unsigned char> twlo = make_twiddle_table(13, e->rs, LO_NT);
