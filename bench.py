@@ -411,7 +411,13 @@ def main():
 
     wl = WORKLOADS[args.workload]
     I, O, L, N, rs, fmt = wl
-    fi, ci, fo, co = sharding.shard_crossbar(I, O, world, rank)
+    # Rehearsal of ONE rank of an N-rank run on a single GPU (BFHIP_BENCH_REHEARSE_RANKS=N): the very
+    # step loop of the N > 1 path -- phase calls, fused [K3 | K1] launch, three buffers in flight --
+    # with the collective replaced by a device copy of this rank's slice.  What a rank costs before
+    # any communication; not a bench line (the metric name says so).
+    rehearse = int(os.environ.get("BFHIP_BENCH_REHEARSE_RANKS", "0")) if world == 1 else 0
+    shards = rehearse if rehearse > 1 else world
+    fi, ci, fo, co = sharding.shard_crossbar(I, O, shards, rank)
 
     eng = bf.Engine(L, N, rs, ci, O, device=dev_index)
     infmts = bf.interleaved_formats(fmt, I)
@@ -450,7 +456,7 @@ def main():
         g.manual_seed(1234)
         raw_in = (torch.randn(n_pool, L, I, generator=g, device=device, dtype=torch.float64) * 0.1).contiguous()
         raw_out = torch.zeros(L, O, dtype=torch.float64, device=device)
-    pipelined = world > 1 and not os.environ.get("BFHIP_BENCH_SYNC_COLLECTIVE")
+    pipelined = shards > 1 and not os.environ.get("BFHIP_BENCH_SYNC_COLLECTIVE")
 
     class _Done:
         """stand-in for a torch Work handle when the collective already ran on the host (gloo)"""
@@ -458,13 +464,16 @@ def main():
             return True
 
     def start_mixdown(zp, zl):
+        if rehearse > 1:
+            zl.copy_(zp[fo:fo + co])                 # stands in for the reduce-scatter, on the compute stream
+            return _Done()
         if backend == "nccl":
             return dist.reduce_scatter_tensor(zl, zp, async_op=True)      # on RCCL's own stream
         torch.cuda.synchronize()
         sharding.mixdown(zp, zl)
         return _Done()
     depth = 3
-    if world > 1:
+    if shards > 1:
         z_part = [torch.zeros(O, L, 2, dtype=tdt, device=device) for _ in range(depth)]
         z_loc = [torch.zeros(co, L, 2, dtype=tdt, device=device) for _ in range(depth)]
     pending = []          # (work handle, buffer index) of blocks whose mix-down is in flight
@@ -485,7 +494,7 @@ def main():
 
     def step(k):
         src = raw_in[k % n_pool]
-        if world == 1:
+        if shards == 1:
             if args.host_io:
                 if _lib.bfhip_engine_rt_submit(eng.h, _in_p[k % n_pool]) < 0:
                     raise RuntimeError(_lib.bfhip_last_error().decode())
@@ -587,9 +596,10 @@ def main():
 
     if rank == 0:
         ms = el * 1e3 / args.steps
-        value = O * L * args.steps / el
+        value = (co if rehearse > 1 else O) * L * args.steps / el      # rehearsal: this rank's outputs only
         out = {
-            "metric": BASELINE_METRIC if args.workload == "C" else "filtered samples/sec",
+            "metric": ("REHEARSAL of one rank of %d (no collective): rank-local samples/sec" % rehearse) if rehearse > 1
+                      else (BASELINE_METRIC if args.workload == "C" else "filtered samples/sec"),
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32" if rs == 4 else "f64",
@@ -609,7 +619,7 @@ def main():
                        "block_schedule": {0: "K1, MAC, K3 in order on one stream",
                                           1: "pipelined: K1 of t+1 and K3 of t-1 on side streams beside the MAC of t",
                                           2: "deferred output: [K3 of t-1 | K1 of t] in one launch, then the MAC of t"
-                                          }.get(eng.block_mode, "?") if world == 1 else "phase calls + fused [K3 | K1] launch",
+                                          }.get(eng.block_mode, "?") if shards == 1 else "phase calls + fused [K3 | K1] launch",
                        "fft": "wave-level (fft_wave.h)" if eng.uses_wave_fft else "LDS Stockham (fft_lds.h)"},
             "hbm_gbs_algorithmic": alg["block"] / (ms * 1e-3) / 1e9 if world == 1 else None,
         }

@@ -3123,7 +3123,7 @@ int bfhip_engine_read_output_spectrum(bfhip_engine *e, int ch, void *dst) {
     std::vector<unsigned char> tmp(row);
     memset(dst, 0, row);
     for (int c = 0; c < e->n_chunks; c++) {
-        const unsigned char *zp = (const unsigned char *)((e->pipelined && e->d_Zp2 && ((e->blocks_done - 1) & 1)) ? e->d_Zp2 : e->d_Zp);
+        const unsigned char *zp = (const unsigned char *)(((e->pipelined || e->defer_out) && e->d_Zp2 && ((e->blocks_done - 1) & 1)) ? e->d_Zp2 : e->d_Zp);
         HIPCHK(hipMemcpy(tmp.data(), zp + ((size_t)c * e->n_out_padded + ch) * row, row, hipMemcpyDeviceToHost));
         const size_t n = (size_t)2 * e->L;
         if (e->rs == 4) for (size_t i = 0; i < n; i++) ((float *)dst)[i] += ((float *)tmp.data())[i];

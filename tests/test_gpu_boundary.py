@@ -480,3 +480,44 @@ def test_stream_ordered_coefficients_follow_runtime_changes(hip, cv, monkeypatch
         assert s1 == 0 and s2 == 0
         assert np.array_equal(g, q), k               # same arithmetic, different memory layout
         assert cases.rel_rms(np.frombuffer(g.tobytes(), dt), np.frombuffer(w.tobytes(), dt)) <= tol, k
+
+
+def test_coefficient_slabs_reserve_overflow_and_error_paths(hip, monkeypatch):
+    """coefficient sets live in slabs (bfhip_engine_reserve_coeffs / 64 MiB + 2 GiB pieces): a
+    reservation that turns out too small spills into a further slab, a rejected set (NaN among the
+    taps) gives its space back, and the layout knobs change no sample"""
+    L, N, I, O = 512, 2, 3, 3
+    blocks = cases.raw_blocks(21, N + 3, L, I, "S16_LE")
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        e = hip.Engine(L, N, 4, I, O)
+        e.set_interleaved(0, "S16_LE")
+        e.set_interleaved(1, "FLOAT_LE")
+        e.reserve_coeffs(4 * N * 2 * L * 4)              # room for 4 of the 9 sets: the rest spills
+        bad = np.ones(L * N, np.float32)
+        bad[7] = np.nan
+        with pytest.raises(hip.BfhipError, match="NaN or Inf"):
+            e.add_coeff(bad)
+        for o in range(O):
+            for i in range(I):
+                h = cases.make_ir(np.random.default_rng(70 + o * I + i), L * N, I)
+                e.add_filter(in_ch=[i], out_ch=[o], coeff=e.add_coeff(h))
+        with pytest.raises(hip.BfhipError, match="NaN or Inf"):
+            e.add_coeff(bad)
+        e.finalize()
+        outs = []
+        for blk in blocks:
+            st, raw = e.block(blk)
+            assert st == 0
+            outs.append(raw.copy())
+        for k in env:
+            monkeypatch.delenv(k)
+        return outs
+
+    base = run({})
+    for env in ({"BFHIP_COEFF_ARENA": "0"}, {"BFHIP_COEFF_SLAB_MB": "1"}, {"BFHIP_COEFF_PAD_B": "4096"},
+                {"BFHIP_COEFF_PAD_B": "r"}):
+        got = run(env)
+        assert all(np.array_equal(a, b) for a, b in zip(base, got)), env
