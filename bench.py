@@ -279,6 +279,16 @@ def cpu_model():
     return "unknown"
 
 
+def _die_with_parent():
+    """in the child, before exec: SIGKILL when the launcher goes away (PR_SET_PDEATHSIG), so a rank
+    never outlives a launcher that was itself killed at a time limit"""
+    try:
+        import ctypes
+        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, 9)
+    except Exception:                                  # noqa: BLE001
+        pass
+
+
 def self_launch(n, argv):
     """`python bench.py --gpus N`, N > 1, started by hand: become the launcher.  This process
     never initialises HIP (no torch.cuda call, no libbfhip call); it starts N fresh rank
@@ -300,7 +310,7 @@ def self_launch(n, argv):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # this pool's driver only does dmabuf IPC
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True,
-                                      start_new_session=True))
+                                      start_new_session=True, preexec_fn=_die_with_parent))
     out0 = []
     reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout.readlines()), daemon=True)
     reader.start()

@@ -243,6 +243,7 @@ struct bfhip_engine {
     int stream_geom[5] = {0, 0, 0, 0, 0};                          // entries, E_c, P, n_tc, n_groups
     bool any_watched = false;
     unsigned long long watch_seq = 0;       // bfhip_coeff_dirty_sequence() at the last poll
+    unsigned long long watch_lost = 0;      // bfhip_dirty_lost() at the last poll
     std::vector<Filter> filters;
     bool finalized = false, plan_dirty = true;
     unsigned int blockcounter = 0;
@@ -1644,12 +1645,15 @@ int poll_coeff_changes(bfhip_engine *e) {
     const unsigned long long seq = bfhip_coeff_dirty_sequence();
     if (seq == e->watch_seq) return 0;
     e->watch_seq = seq;
+    const unsigned long long lost = bfhip_dirty_lost();
+    const bool all = lost != e->watch_lost;             // a notice found no slot: trust nothing
+    e->watch_lost = lost;
     int n = 0;
     for (size_t ci = 0; ci < e->coeffs.size(); ci++) {
         Coeff &c = e->coeffs[ci];
         for (size_t b = 0; b < c.watch_src.size(); b++) {
             const uint64_t gen = bfhip_dirty_generation(c.watch_src[b]);
-            if (gen == c.watch_gen[b]) continue;
+            if (gen == c.watch_gen[b] && !all) continue;
             c.watch_gen[b] = gen;
             const int r = bfhip_engine_refresh_coeff_processed(e, (int)ci, (int)b, c.watch_src[b]);
             if (r != BFHIP_OK) return r;
@@ -3030,6 +3034,7 @@ int bfhip_engine_set_status_dev(bfhip_engine *e, int *status_dev) {
 int bfhip_engine_set_stream(bfhip_engine *e, void *hip_stream) {
     if (!e) return fail(BFHIP_EINVAL, "null engine");
     HIPCHK(hipSetDevice(e->device));
+    if (e->finalized) { int _r = flush_pending(e); if (_r != BFHIP_OK) return _r; }
     { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     e->stream = (hipStream_t)hip_stream;

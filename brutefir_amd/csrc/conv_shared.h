@@ -24,10 +24,12 @@ struct bfhip_dirty_slot { uintptr_t addr; uint64_t gen; };
 #define BFHIP_DIRTY_SLOTS 8192
 struct bfhip_dirty_table {
     uint64_t seq;                                   // bumped by every notice
+    uint64_t lost;                                  // notices that found no slot: watchers re-read everything
     struct bfhip_dirty_slot slot[BFHIP_DIRTY_SLOTS];
 };
 struct bfhip_dirty_table *bfhip_dirty_table_get(void);    // NULL before convolver_init()
 uint64_t bfhip_dirty_generation(const void *cbuf);         // 0 = never marked
+uint64_t bfhip_dirty_lost(void);                           // notices the table had no room for
 
 }  // extern "C"
 

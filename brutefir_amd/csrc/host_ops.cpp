@@ -159,9 +159,14 @@ void bfhip_coeff_mark_dirty(const void *cbuf) {
             return;
         }
     }
-    /* table full (more than 8192 distinct partitions rewritten at run time): the global
-       sequence still moves, watchers then re-read everything they watch */
-    __atomic_add_fetch(&g_dirty->seq, BFHIP_DIRTY_SLOTS, __ATOMIC_RELEASE);
+    /* table full (more than 8192 distinct partitions rewritten at run time): count the notice
+       as lost -- watchers that see the counter move re-read everything they watch */
+    __atomic_add_fetch(&g_dirty->lost, 1, __ATOMIC_RELEASE);
+    __atomic_add_fetch(&g_dirty->seq, 1, __ATOMIC_RELEASE);
+}
+
+uint64_t bfhip_dirty_lost(void) {
+    return g_dirty ? __atomic_load_n(&g_dirty->lost, __ATOMIC_ACQUIRE) : 0;
 }
 
 uint64_t bfhip_dirty_generation(const void *cbuf) {
