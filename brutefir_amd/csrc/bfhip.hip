@@ -2979,6 +2979,16 @@ int bfhip_engine_rt_stats(const bfhip_engine *e, unsigned long long *graph_block
     return BFHIP_OK;
 }
 
+// ---- self test of the wave FFT's host half: its per-thread twiddle table, no device involved ----
+int bfhip_selftest_wave_twiddles(int log2l, int realsize, void *out, int out_bytes) {
+    if (!wave_fft_ok(log2l, realsize)) return fail(BFHIP_EINVAL, "selftest_wave_twiddles: length / precision not covered");
+    const std::vector<unsigned char> t = make_wave_twiddle_table(log2l, realsize);
+    if (out == nullptr) return (int)t.size();
+    if ((size_t)out_bytes < t.size()) return fail(BFHIP_EINVAL, "selftest_wave_twiddles: buffer too small");
+    memcpy(out, t.data(), t.size());
+    return (int)t.size();
+}
+
 // ---- self test of the host-side delay machine: no device involved ---------------------------
 struct bfhip_selftest_delay { DelayLine dl; };
 

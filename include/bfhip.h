@@ -347,6 +347,12 @@ int bfhip_engine_read_ring_slot(bfhip_engine *e, int in_channel, int slot, void 
  * host and has the device execute the moves it emits.  These three calls run the same machine
  * with its buffers in host memory, so that its output can be checked against delay.c without a
  * GPU (tests/test_abi.py).  update returns the number of moves, or a negative error. */
+/* The wave-level FFT (csrc/fft_wave.h) reads its twiddles from a host-made table whose second
+   part is ordered by thread and register: [0, 2L) exp(-2 pi i m / 2L), then 18 registers x L/16
+   threads.  This call returns the table (or, with out == NULL, its size in bytes) so that the
+   thread -> butterfly maps it encodes can be checked against a model of the algorithm without a
+   GPU (tests/test_wave_fft_model.py). */
+int bfhip_selftest_wave_twiddles(int log2l, int realsize, void *out, int out_bytes);
 typedef struct bfhip_selftest_delay bfhip_selftest_delay;
 bfhip_selftest_delay *bfhip_selftest_delay_new(int fragment, int initdelay, int maxdelay, int sample_size);
 int bfhip_selftest_delay_update(bfhip_selftest_delay *d, void *buf /* fragment * sample_size bytes */, int delay);
