@@ -2672,6 +2672,7 @@ int bfhip_engine_inputs_dev(bfhip_engine *e, const void *rawin_dev) {
 int bfhip_engine_mac_dev(bfhip_engine *e, void *z_dev) {
     int r = ensure_ready(e);
     if (r != BFHIP_OK) return r;
+    if ((r = flush_pending(e)) != BFHIP_OK) return r;      // an output owed by bfhip_engine_block_dev goes first
     e->ls = e->stream;
     timing_begin(e);
     if ((r = do_levels(e)) != BFHIP_OK) return r;
@@ -2692,6 +2693,7 @@ int bfhip_engine_mac_dev(bfhip_engine *e, void *z_dev) {
 int bfhip_engine_outputs_dev(bfhip_engine *e, const void *z_dev, int first, int count, void *rawout_dev) {
     int r = ensure_ready(e);
     if (r != BFHIP_OK) return r;
+    if ((r = flush_pending(e)) != BFHIP_OK) return r;      // an output owed by bfhip_engine_block_dev goes first
     if (first < 0 || count < 0 || first + count > e->n_ch[1]) return fail(BFHIP_EINVAL, "outputs: channel range");
     e->ls = e->stream;
     timing_begin(e);
@@ -2704,6 +2706,7 @@ int bfhip_engine_outputs_inputs_dev(bfhip_engine *e, const void *z_dev, int firs
                                     void *rawout_dev, const void *rawin_dev) {
     int r = ensure_ready(e);
     if (r != BFHIP_OK) return r;
+    if ((r = flush_pending(e)) != BFHIP_OK) return r;      // an output owed by bfhip_engine_block_dev goes first
     if (first < 0 || count < 0 || first + count > e->n_ch[1]) return fail(BFHIP_EINVAL, "outputs: channel range");
     if (!e->dither_channels.empty() || e->has_vchan || count == 0 || e->big) {
         // the dither pass follows the inverse transforms: keep the two launches apart
