@@ -639,7 +639,7 @@ def main():
         if world == 1:
             traffic, traffic_stale, traffic_src = None, None, None
             tp = os.path.join(ROOT, "profiles", "traffic_config%s.json" % args.workload)
-            if os.path.exists(tp):
+            if os.path.exists(tp) and rehearse <= 1:
                 # HBM bytes per MAC launch from the committed rocprofv3 PMC passes of this very
                 # workload (counters cannot be read from inside this process).  The file names
                 # the sources it was measured on; a different binary is flagged, not trusted.
