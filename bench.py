@@ -569,7 +569,9 @@ def main():
     fence()
     # per-kernel HIP events on every 4th block of the timed region: the records themselves
     # cost the stream ~20 us per block, which would otherwise be charged to `value`
-    eng.enable_timing(0 if os.environ.get("BFHIP_BENCH_NO_EVENTS") else (4 if args.steps >= 32 else 1))
+    # (small crossbars are bound by the host's launch rate: there every 16th block only)
+    stride = (16 if eng.block_mode in (1, 3) else 4) if args.steps >= 32 else 1
+    eng.enable_timing(0 if os.environ.get("BFHIP_BENCH_NO_EVENTS") else stride)
     timed[0] = True
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -628,7 +630,8 @@ def main():
                        "status_bits": status if per_rank is None else max(p["status_bits"] for p in per_rank),
                        "block_schedule": {0: "K1, MAC, K3 in order on one stream",
                                           1: "pipelined: K1 of t+1 and K3 of t-1 on side streams beside the MAC of t",
-                                          2: "deferred output: [K3 of t-1 | K1 of t] in one launch, then the MAC of t"
+                                          2: "deferred output: [K3 of t-1 | K1 of t] in one launch, then the MAC of t",
+                                          3: "ping-pong: [K3 of t-2 | K1 of t] on a side stream beside the MAC of t-1"
                                           }.get(eng.block_mode, "?") if shards == 1 else "phase calls + fused [K3 | K1] launch",
                        "fft": "wave-level (fft_wave.h)" if eng.uses_wave_fft else "LDS Stockham (fft_lds.h)"},
             "hbm_gbs_algorithmic": alg["block"] / (ms * 1e-3) / 1e9 if world == 1 else None,
@@ -650,7 +653,7 @@ def main():
             rf = mac_roofline(tm, alg["mac"])
             rf.update({"traffic": traffic, "traffic_stale": traffic_stale, "traffic_source_hash": traffic_src,
                        "launches": args.steps, "fft_in_ms": tm["fft_in_ms"], "ifft_out_ms": tm["ifft_out_ms"]})
-            if eng.block_mode == 2:
+            if eng.block_mode in (2, 3):
                 rf["fft_note"] = "fft_in_ms is the fused [K3 of t-1 | K1 of t] launch; there is no separate K3 launch"
             out["roofline"] = rf
             if not args.no_cpu_baseline:

@@ -412,7 +412,8 @@ class Engine:
 
     @property
     def block_mode(self):
-        """0 sequential, 1 pipelined (side streams), 2 deferred output (fused K3|K1 launch)"""
+        """0 sequential, 1 pipelined (three streams), 2 deferred output (fused K3|K1 launch),
+        3 ping-pong (fused K3|K1 launch on a side stream beside the previous MAC)"""
         return lib().bfhip_engine_block_mode(self.h)
 
     @property

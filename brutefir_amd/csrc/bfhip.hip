@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstring>
 #include <ctime>
+#include <deque>
 #include <map>
 #include <string>
 #include <vector>
@@ -268,11 +269,19 @@ struct bfhip_engine {
     // and behind the millisecond MAC.  The output of a block is therefore written during the
     // NEXT bfhip_engine_block_dev call, or by bfhip_engine_sync (which flushes it).
     bool defer_out = false;            // decided at finalize (BFHIP_DEFER=0/1 forces)
+    // Two-stream ping-pong (small crossbars with the wave FFT): [K3 of t-2 | K1 of t] in one launch
+    // on the side stream s_in while the MAC of t-1 runs on the main stream; the MAC of t waits for
+    // that launch.  Two launches and four event calls per block instead of three launches and
+    // seven, and the two transforms run side by side.  Outputs are owed for two calls.
+    bool pipe2 = false;                // decided at finalize (BFHIP_PIPE2=0 keeps the three-stream schedule)
+    void *d_Zp3 = nullptr;
+    hipEvent_t ev_io[2] = {nullptr, nullptr}, ev_mac3[3] = {nullptr, nullptr, nullptr};
     struct Pending {
-        bool on = false;
         void *Zp = nullptr; size_t chunk_stride = 0; int n_chunks = 0;
         void *rawout = nullptr; hipEvent_t out_done = nullptr;
-    } pend;
+        hipEvent_t mac_done = nullptr;     // pipe2: the side stream waits for it before the inverse transforms
+    };
+    std::deque<Pending> pendq;         // outputs owed, oldest first (deferred: at most 1, pipe2: at most 2)
 
     // partition lengths above the LDS limit (bigfft.h): global scratch for [transform][L] complex
     bool big = false;
@@ -1278,9 +1287,11 @@ int build_plan_t(bfhip_engine *e) {
     if (zb > e->zp_bytes) {
         if (e->d_Zp) (void)hipFree(e->d_Zp);
         if (e->d_Zp2) (void)hipFree(e->d_Zp2);
-        e->d_Zp2 = nullptr;
+        if (e->d_Zp3) (void)hipFree(e->d_Zp3);
+        e->d_Zp2 = nullptr; e->d_Zp3 = nullptr;
         HIPCHK(hipMalloc(&e->d_Zp, zb));
         if (e->pipelined || e->defer_out) HIPCHK(hipMalloc(&e->d_Zp2, zb));
+        if (e->pipe2) HIPCHK(hipMalloc(&e->d_Zp3, zb));
         e->zp_bytes = zb;
     }
 
@@ -1379,22 +1390,28 @@ int poll_coeff_changes(bfhip_engine *e);
 int do_outputs(bfhip_engine *e, const void *Zp, size_t chunk_stride, int n_chunks, int first,
                int count, void *rawout_dev);
 
-// the inverse transforms of the block whose output is still owed (deferred output), on their own
+// the inverse transforms of the blocks whose output is still owed (deferred output: one, ping-pong
+// schedule: up to two), oldest first, each as a launch of its own
 int flush_pending(bfhip_engine *e) {
-    if (!e->pend.on) return BFHIP_OK;
-    e->pend.on = false;
+    while (!e->pendq.empty()) {
+        const bfhip_engine::Pending p = e->pendq.front();
+        e->pendq.pop_front();
+        // the ping-pong schedule keeps every output pass on the side stream (their overflow state
+        // and the dither chains are sequential), behind the MAC that produced the spectra
+        e->ls = e->pipe2 ? e->s_in : e->stream;
+        if (p.mac_done) HIPCHK(hipStreamWaitEvent(e->ls, p.mac_done, 0));
+        const int r = do_outputs(e, p.Zp, p.chunk_stride, p.n_chunks, 0, e->n_ch[1], p.rawout);
+        if (r != BFHIP_OK) { e->ls = e->stream; return r; }
+        if (p.out_done) HIPCHK(hipEventRecord(p.out_done, e->ls));
+    }
     e->ls = e->stream;
-    const int r = do_outputs(e, e->pend.Zp, e->pend.chunk_stride, e->pend.n_chunks, 0, e->n_ch[1], e->pend.rawout);
-    if (r != BFHIP_OK) return r;
-    if (e->pend.out_done) HIPCHK(hipEventRecord(e->pend.out_done, e->stream));
-    e->pend.out_done = nullptr;
     return BFHIP_OK;
 }
 
 int ensure_ready(bfhip_engine *e) {
     if (!e->finalized) return fail(BFHIP_ESTATE, "engine not finalized");
     HIPCHK(hipSetDevice(e->device));
-    if (e->plan_dirty && e->pend.on) {
+    if (e->plan_dirty && !e->pendq.empty()) {
         // the owed output belongs to the old plan's geometry and buffers
         const int r = flush_pending(e);
         if (r != BFHIP_OK) return r;
@@ -1944,7 +1961,7 @@ bfhip_engine *bfhip_engine_create(int device, int length, int n_blocks, int real
 void bfhip_engine_destroy(bfhip_engine *e) {
     if (e == nullptr) return;
     (void)hipSetDevice(e->device);
-    e->pend.on = false;
+    e->pendq.clear();
     (void)sync_all(e);
     if (e->coeff_arena) { for (auto &sl : e->slabs) if (sl.base) (void)hipFree(sl.base); }
     else { for (auto &c : e->coeffs) if (c.d_H) (void)hipFree(c.d_H); }
@@ -1961,7 +1978,10 @@ void bfhip_engine_destroy(bfhip_engine *e) {
         if (e->ev_in[i]) (void)hipEventDestroy(e->ev_in[i]);
         if (e->ev_mac[i]) (void)hipEventDestroy(e->ev_mac[i]);
         if (e->ev_out[i]) (void)hipEventDestroy(e->ev_out[i]);
+        if (e->ev_io[i]) (void)hipEventDestroy(e->ev_io[i]);
     }
+    for (int i = 0; i < 3; i++) if (e->ev_mac3[i]) (void)hipEventDestroy(e->ev_mac3[i]);
+    if (e->d_Zp3) (void)hipFree(e->d_Zp3);
     if (e->s_in) (void)hipStreamDestroy(e->s_in);
     if (e->s_out) (void)hipStreamDestroy(e->s_out);
     if (e->d_status_own) e->d_status = e->d_status_own;
@@ -2398,7 +2418,9 @@ int bfhip_engine_finalize(bfhip_engine *e) {
         // another.  Not the default.  With the 1024-thread kernels on the side streams the MAC's
         // workgroups used to be pushed together on fewer CUs: 1.74 ms.)
         if (e->overlap_mode >= 0) { e->pipelined = e->overlap_mode != 0; e->lowfoot = e->lowfoot && e->pipelined; }
-        if (const char *env = getenv("BFHIP_OVERLAP")) {       // 0 off, 1 on (full-size kernels), 2 on (narrow kernels)
+        // (the environment only moves the AUTOMATIC choice: an explicit bfhip_engine_set_overlap wins --
+        // the non-uniform convolver depends on its segment engines running strictly in order)
+        if (const char *env = e->overlap_mode < 0 ? getenv("BFHIP_OVERLAP") : nullptr) {       // 0 off, 1 on (full-size kernels), 2 on (narrow kernels)
             e->pipelined = atoi(env) != 0;
             e->lowfoot = atoi(env) == 2 && e->log2L == 13 && e->rs == 4;
         }
@@ -2413,6 +2435,9 @@ int bfhip_engine_finalize(bfhip_engine *e) {
         // (an explicit bfhip_engine_set_overlap(e, 0) -- "strictly in order" -- beats the environment:
         // the non-uniform convolver relies on it for its segment engines)
         if (const char *env = getenv("BFHIP_DEFER")) e->defer_out = atoi(env) != 0 && !e->pipelined && plain && e->overlap_mode != 0;
+        // small MACs with the wave FFT: the two-stream ping-pong instead of three streams
+        e->pipe2 = e->pipelined && plain && !e->lowfoot;
+        if (const char *env = getenv("BFHIP_PIPE2")) e->pipe2 = e->pipe2 && atoi(env) != 0;
     }
     if (e->lowfoot) {
         const std::vector<unsigned char> twlo = make_twiddle_table(13, e->rs, LO_NT);
@@ -2574,7 +2599,9 @@ int bfhip_engine_finalize(bfhip_engine *e) {
             HIPCHK(hipEventCreateWithFlags(&e->ev_in[i], hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&e->ev_mac[i], hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&e->ev_out[i], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&e->ev_io[i], hipEventDisableTiming));
         }
+        for (int i = 0; i < 3; i++) HIPCHK(hipEventCreateWithFlags(&e->ev_mac3[i], hipEventDisableTiming));
     }
     e->ls = e->stream;
     e->finalized = true;
@@ -2751,21 +2778,73 @@ static int block_dev_impl(bfhip_engine *e, const void *rawin_dev, void *rawout_d
     void *Zp = ((pipe || e->defer_out) && buf) ? e->d_Zp2 : e->d_Zp;
     timing_begin(e);
 
+    if (e->pipe2) {
+        // side stream: [K3 of block t-2 | K1 of block t]; main stream: MAC of block t behind it.  The
+        // MAC of t-1 (main) and this launch (side) overlap: K1 fills the spare ring slot, K3 reads the
+        // third Zp buffer.
+        const int zi = (int)(e->blocks_done % 3ull), par = (int)(e->blocks_done & 1ull);
+        void *Zq = zi == 0 ? e->d_Zp : (zi == 1 ? e->d_Zp2 : e->d_Zp3);
+        e->ls = e->s_in;
+        if (in_ready) HIPCHK(hipStreamWaitEvent(e->s_in, in_ready, 0));
+        if ((r = record(e, 0)) != BFHIP_OK) return r;
+        if (e->pendq.size() >= 2) {
+            const bfhip_engine::Pending p = e->pendq.front();
+            e->pendq.pop_front();
+            HIPCHK(hipStreamWaitEvent(e->s_in, p.mac_done, 0));
+            if (p.n_chunks <= 2) {
+                hipError_t err = hipSuccess;
+                const int slot = (int)(e->blockcounter % (unsigned int)e->R);
+                DISPATCH_WAVE(launch_io_wave, e, p.Zp, p.chunk_stride, p.n_chunks, 0, e->n_ch[1],
+                              (uint8_t *)p.rawout, (const uint8_t *)rawin_dev, slot, &err)
+                if (err != hipSuccess) return fail(BFHIP_EHIP, "io launch: %s", hipGetErrorString(err));
+            } else {
+                if ((r = do_outputs(e, p.Zp, p.chunk_stride, p.n_chunks, 0, e->n_ch[1], p.rawout)) != BFHIP_OK) return r;
+                if ((r = do_inputs(e, rawin_dev)) != BFHIP_OK) return r;
+            }
+            if (p.out_done) HIPCHK(hipEventRecord(p.out_done, e->s_in));
+        } else {
+            if ((r = do_inputs(e, rawin_dev)) != BFHIP_OK) return r;
+        }
+        if ((r = record(e, 1)) != BFHIP_OK) return r;
+        HIPCHK(hipEventRecord(e->ev_io[par], e->s_in));
+        e->ls = e->stream;
+        HIPCHK(hipStreamWaitEvent(e->stream, e->ev_io[par], 0));
+        if ((r = do_levels(e)) != BFHIP_OK) return r;
+        if ((r = record(e, 2)) != BFHIP_OK) return r;
+        if ((r = do_mac(e, Zq)) != BFHIP_OK) return r;
+        if ((r = record(e, 3)) != BFHIP_OK) return r;
+        bfhip_engine::Pending np;
+        np.Zp = Zq; np.chunk_stride = (size_t)e->n_out_padded * e->L; np.n_chunks = e->n_chunks;
+        if (e->n_chunks > 2) {
+            // many partials (few long filters): add them up with the whole chip here, in place, so that
+            // the fused transform launch reads one spectrum per channel
+            hipError_t err = hipSuccess;
+            if (e->rs == 4) launch_sum<float>(e, Zq, Zq, &err); else launch_sum<double>(e, Zq, Zq, &err);
+            if (err != hipSuccess) return fail(BFHIP_EHIP, "sum_partials launch: %s", hipGetErrorString(err));
+            np.n_chunks = 1;
+        }
+        HIPCHK(hipEventRecord(e->ev_mac3[zi], e->stream));
+        np.rawout = rawout_dev; np.out_done = out_done; np.mac_done = e->ev_mac3[zi];
+        e->pendq.push_back(np);
+        advance(e);
+        return BFHIP_OK;
+    }
+
     if (e->defer_out && !pipe) {
         // [K3 of block t-1 | K1 of block t] in one launch, then the MAC of block t; K3 of block t is
         // owed to the next call (or to sync).  Same kernels, same order per channel: same bits.
         e->ls = e->stream;
         if (in_ready) HIPCHK(hipStreamWaitEvent(e->stream, in_ready, 0));
         if ((r = record(e, 0)) != BFHIP_OK) return r;
-        if (e->pend.on && e->pend.n_chunks <= 2) {
+        if (!e->pendq.empty() && e->pendq.front().n_chunks <= 2) {
+            const bfhip_engine::Pending p = e->pendq.front();
+            e->pendq.pop_front();
             hipError_t err = hipSuccess;
             const int slot = (int)(e->blockcounter % (unsigned int)e->R);
-            DISPATCH_WAVE(launch_io_wave, e, e->pend.Zp, e->pend.chunk_stride, e->pend.n_chunks, 0, e->n_ch[1],
-                          (uint8_t *)e->pend.rawout, (const uint8_t *)rawin_dev, slot, &err)
+            DISPATCH_WAVE(launch_io_wave, e, p.Zp, p.chunk_stride, p.n_chunks, 0, e->n_ch[1],
+                          (uint8_t *)p.rawout, (const uint8_t *)rawin_dev, slot, &err)
             if (err != hipSuccess) return fail(BFHIP_EHIP, "io launch: %s", hipGetErrorString(err));
-            e->pend.on = false;
-            if (e->pend.out_done) HIPCHK(hipEventRecord(e->pend.out_done, e->stream));
-            e->pend.out_done = nullptr;
+            if (p.out_done) HIPCHK(hipEventRecord(p.out_done, e->stream));
         } else {
             if ((r = flush_pending(e)) != BFHIP_OK) return r;
             if ((r = do_inputs(e, rawin_dev)) != BFHIP_OK) return r;
@@ -2775,9 +2854,10 @@ static int block_dev_impl(bfhip_engine *e, const void *rawin_dev, void *rawout_d
         if ((r = record(e, 2)) != BFHIP_OK) return r;
         if ((r = do_mac(e, Zp)) != BFHIP_OK) return r;
         if ((r = record(e, 3)) != BFHIP_OK) return r;
-        e->pend.on = true;
-        e->pend.Zp = Zp; e->pend.chunk_stride = (size_t)e->n_out_padded * e->L; e->pend.n_chunks = e->n_chunks;
-        e->pend.rawout = rawout_dev; e->pend.out_done = out_done;
+        bfhip_engine::Pending np;
+        np.Zp = Zp; np.chunk_stride = (size_t)e->n_out_padded * e->L; np.n_chunks = e->n_chunks;
+        np.rawout = rawout_dev; np.out_done = out_done; np.mac_done = nullptr;
+        e->pendq.push_back(np);
         advance(e);
         return BFHIP_OK;
     }
@@ -2837,6 +2917,7 @@ int bfhip_engine_block(bfhip_engine *e, const void *rawin, void *rawout, bfhip_o
     if (!rawin || !rawout) return fail(BFHIP_EINVAL, "block: null buffer");
     static_assert(sizeof(bfhip_overflow) == sizeof(DevOverflow), "overflow struct layout");
     hipStream_t sin = e->pipelined ? e->s_in : e->stream, sout = e->pipelined ? e->s_out : e->stream;
+    if (e->pipe2) sout = e->s_in;              // the ping-pong schedule keeps the output passes on the side stream
     if (overflow) HIPCHK(hipMemcpyAsync(e->d_over, overflow, e->n_ch[1] * sizeof(DevOverflow), hipMemcpyHostToDevice, sout));
     HIPCHK(hipMemcpyAsync(e->d_rawin, rawin, e->raw_bytes[0], hipMemcpyHostToDevice, sin));
     if ((r = bfhip_engine_block_dev(e, e->d_rawin, e->d_rawout)) != BFHIP_OK) return r;
@@ -2853,6 +2934,7 @@ int bfhip_engine_rt_begin(bfhip_engine *e, int flags) {
     if (e->rt.on) return fail(BFHIP_ESTATE, "rt_begin: already in real-time mode");
     if ((r = sync_all(e)) != BFHIP_OK) return r;
     e->pipelined = false;                      // one stream: a period is needed back as soon as possible
+    e->pipe2 = false;
     auto &rt = e->rt;
     rt.flags = flags;
     for (int p = 0; p < 2; p++) {
@@ -3081,6 +3163,7 @@ int bfhip_engine_reset_overflow(bfhip_engine *e) {
 unsigned int bfhip_engine_blockcounter(const bfhip_engine *e) { return e ? e->blockcounter : 0; }
 int bfhip_engine_block_mode(const bfhip_engine *e) {
     if (!e || !e->finalized) return -1;
+    if (e->pipe2) return BFHIP_MODE_PINGPONG;
     return e->pipelined ? BFHIP_MODE_PIPELINED : (e->defer_out ? BFHIP_MODE_DEFERRED : BFHIP_MODE_SEQUENTIAL);
 }
 int bfhip_engine_uses_wave_fft(const bfhip_engine *e) { return e && e->wave ? 1 : 0; }
@@ -3142,6 +3225,10 @@ int bfhip_engine_read_output_spectrum(bfhip_engine *e, int ch, void *dst) {
     memset(dst, 0, row);
     for (int c = 0; c < e->n_chunks; c++) {
         const unsigned char *zp = (const unsigned char *)(((e->pipelined || e->defer_out) && e->d_Zp2 && ((e->blocks_done - 1) & 1)) ? e->d_Zp2 : e->d_Zp);
+        if (e->pipe2) {
+            const int zi = (int)((e->blocks_done - 1) % 3ull);
+            zp = (const unsigned char *)(zi == 0 ? e->d_Zp : (zi == 1 ? e->d_Zp2 : e->d_Zp3));
+        }
         HIPCHK(hipMemcpy(tmp.data(), zp + ((size_t)c * e->n_out_padded + ch) * row, row, hipMemcpyDeviceToHost));
         const size_t n = (size_t)2 * e->L;
         if (e->rs == 4) for (size_t i = 0; i < n; i++) ((float *)dst)[i] += ((float *)tmp.data())[i];

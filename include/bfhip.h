@@ -221,7 +221,8 @@ int bfhip_engine_block_dev(bfhip_engine *e, const void *rawin_dev, void *rawout_
        until the NEXT block call has returned: for large crossbars on one stream the inverse
        transforms of a block share one launch with the forward transforms of the next block
        ("deferred output"; bfhip_engine_sync flushes what is owed; bfhip_engine_set_overlap(e, 0)
-       or BFHIP_DEFER=0 turn it off).
+       or BFHIP_DEFER=0 turn it off); small crossbars on the wave FFT owe their output for TWO calls
+       (ping-pong schedule, BFHIP_MODE_PINGPONG; BFHIP_PIPE2=0 turns it off).
    A caller that produces the input or consumes the output asynchronously uses the variant
    below instead: in_ready_event (hipEvent_t, may be NULL) is an event the caller recorded behind
    its producer of rawin_dev -- the input transform waits for it, nothing else does, so the
@@ -314,6 +315,8 @@ unsigned int bfhip_engine_blockcounter(const bfhip_engine *e);
 #define BFHIP_MODE_SEQUENTIAL 0   /* K1, MAC, K3 of a block in order on one stream                 */
 #define BFHIP_MODE_PIPELINED  1   /* small MACs: K1 of t+1 and K3 of t-1 on side streams beside MAC t */
 #define BFHIP_MODE_DEFERRED   2   /* large MACs: [K3 of t-1 | K1 of t] in one launch, then MAC t     */
+#define BFHIP_MODE_PINGPONG   3   /* small MACs, wave FFT: [K3 of t-2 | K1 of t] on a side stream beside
+                                     MAC t-1, MAC t behind it; outputs are owed for two calls         */
 int bfhip_engine_block_mode(const bfhip_engine *e);
 /* 1 if the input / output transforms run on the wave-level FFT (fft_wave.h) */
 int bfhip_engine_uses_wave_fft(const bfhip_engine *e);

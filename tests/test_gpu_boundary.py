@@ -249,7 +249,8 @@ assert got == "106", got
     assert "child fatal code 106" in r.stdout
 
 
-def test_block_dev_ev_orders_an_asynchronous_producer_and_consumer(hip):
+@pytest.mark.parametrize("L", [2048, 4096])       # 2048: three-stream pipeline; 4096: wave FFT -> ping-pong schedule
+def test_block_dev_ev_orders_an_asynchronous_producer_and_consumer(hip, L):
     """The ordering contract of bfhip_engine_block_dev (include/bfhip.h): with the pipelined
     block (overlap forced on) K1 runs on a side stream that does not follow the caller's
     stream.  A producer that fills the SAME input buffer on its own stream right before every
@@ -258,7 +259,7 @@ def test_block_dev_ev_orders_an_asynchronous_producer_and_consumer(hip):
     host synchronisation anywhere in the loop.  Result must equal the plain synchronous engine
     bit for bit."""
     import torch
-    L, N, I, O = 2048, 4, 4, 4
+    N, I, O = 4, 4, 4
     dev = torch.device("cuda", 0)
     ref_e, _ = cases.crossbar(hip.Engine, L, N, 4, I, O, "S24_4LE", "FLOAT_LE")
     blocks = cases.raw_blocks(31, N + 6, L, I, "S24_4LE")
@@ -282,6 +283,8 @@ def test_block_dev_ev_orders_an_asynchronous_producer_and_consumer(hip):
 
     for overlap in (1, 0):
         e = build(overlap)
+        assert e.block_mode == ((3 if L >= 4096 else 1) if overlap else 0)
+        owed = 2 if e.block_mode == 3 else 0              # the ping-pong schedule writes block k during call k+2
         side = torch.cuda.Stream()
         pinned = [torch.from_numpy(b).pin_memory() for b in blocks]
         rawin = torch.zeros(L, I, dtype=torch.int32, device=dev)          # ONE buffer, reused
@@ -293,16 +296,25 @@ def test_block_dev_ev_orders_an_asynchronous_producer_and_consumer(hip):
         for ev in ready + done:
             ev.record(side)                                               # creates the hipEvent_t handles
         torch.cuda.synchronize()
+        # one input buffer per block here: with outputs owed for two calls `done[k]` (which also
+        # releases the input of block k) fires too late to reuse ONE input buffer without stalling
+        rawins = [torch.zeros(L, I, dtype=torch.int32, device=dev) for _ in blocks] if owed else [rawin] * len(blocks)
+        rawouts = [torch.zeros(L, O, dtype=torch.float32, device=dev) for _ in range(3)] if owed else [rawout]
         with torch.cuda.stream(side):
             for k in range(len(blocks)):
-                if k > 0:
+                if k > 0 and not owed:
                     side.wait_event(done[k - 1])                          # rawin may be rewritten now
                 big.fill_(k)                                              # keeps the producer stream busy
-                rawin.copy_(pinned[k], non_blocking=True)
+                rawins[k].copy_(pinned[k], non_blocking=True)
                 ready[k].record(side)
-                e.block_dev_ev(rawin, rawout, ready[k].cuda_event, done[k].cuda_event)
-                side.wait_event(done[k])
-                keep[k].copy_(rawout, non_blocking=True)
+                e.block_dev_ev(rawins[k], rawouts[k % len(rawouts)], ready[k].cuda_event, done[k].cuda_event)
+                j = k - owed                                              # the block whose output this call wrote
+                if j >= 0:
+                    side.wait_event(done[j])
+                    keep[j].copy_(rawouts[j % len(rawouts)], non_blocking=True)
+            assert e.sync() == 0                                          # flushes what is still owed
+            for j in range(len(blocks) - owed, len(blocks)):
+                keep[j].copy_(rawouts[j % len(rawouts)], non_blocking=True)
         torch.cuda.synchronize()
         assert e.sync() == 0
         for k in range(len(blocks)):

@@ -14,9 +14,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_feature_and_fuzz_suites_with_every_fast_path_forced(hip):
-    env = dict(os.environ, BFHIP_FFT_WAVE="1", BFHIP_COEFF_STREAM="2", BFHIP_DEFER="1", BFHIP_OVERLAP="0",
-               BFHIP_FUZZ_SEEDS="12")
+@pytest.mark.parametrize("schedule", ["deferred", "pingpong"])
+def test_feature_and_fuzz_suites_with_every_fast_path_forced(hip, schedule):
+    env = dict(os.environ, BFHIP_FFT_WAVE="1", BFHIP_COEFF_STREAM="2", BFHIP_FUZZ_SEEDS="12")
+    if schedule == "deferred":
+        env.update(BFHIP_DEFER="1", BFHIP_OVERLAP="0")     # [K3 of t-1 | K1 of t] fused, one stream
+    else:
+        env.update(BFHIP_OVERLAP="1")                      # [K3 of t-2 | K1 of t] on a side stream beside the MAC
     files = ["test_gpu_engine.py", "test_gpu_features.py", "test_gpu_fuzz.py", "test_gpu_refconfigs.py",
              "test_gpu_numpy.py", "test_gpu_fullsize.py", "test_gpu_rt.py"]
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"] +
