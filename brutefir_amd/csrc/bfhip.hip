@@ -2431,7 +2431,7 @@ int bfhip_engine_finalize(bfhip_engine *e) {
         // with the input pass of the next one (deferred output).  Needs the plain 1:1 raw path.
         bool plain = e->wave && !e->big && e->sdf_length <= 0 && e->dither_channels.empty();
         for (int io = 0; io < 2; io++) for (int c : e->n_vpp[io]) if (c > 1) plain = false;
-        e->defer_out = !e->pipelined && plain && e->overlap_mode != 0 && bytes / 6.4e12 >= 100e-6;
+        e->defer_out = !e->pipelined && plain && e->overlap_mode != 0;
         // (an explicit bfhip_engine_set_overlap(e, 0) -- "strictly in order" -- beats the environment:
         // the non-uniform convolver relies on it for its segment engines)
         if (const char *env = getenv("BFHIP_DEFER")) e->defer_out = atoi(env) != 0 && !e->pipelined && plain && e->overlap_mode != 0;
