@@ -184,3 +184,22 @@ def test_td_new_needs_no_device(cv):
     taps = np.ones(5, np.float32)
     assert cv.convolver_td_new(p(taps), 5)
     assert cv.convolver_td_new(p(taps), 0) is None
+
+
+def test_host_ops_under_address_and_ub_sanitizers(tmp_path):
+    """The GPU pool has no device sanitizer, the host half can have one: csrc/host_ops.cpp and a
+    driver that walks its entry points (tests/chost/host_ops_driver.cpp) are compiled with
+    -fsanitize=address,undefined and run; any finding aborts the run."""
+    exe = str(tmp_path / "host_ops_asan")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+           "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "brutefir_amd", "csrc", "host_ops.cpp"),
+           os.path.join(ROOT, "tests", "chost", "host_ops_driver.cpp"), "-o", exe]
+    b = subprocess.run(cmd, capture_output=True, text=True)
+    if b.returncode != 0 and "sanitize" in b.stderr:
+        pytest.skip("no sanitizer runtime in this toolchain: " + b.stderr[-200:])
+    assert b.returncode == 0, b.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))     # coefficient memory is never freed by design
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    assert "host_ops_driver: clean" in r.stdout

@@ -53,13 +53,56 @@ def one(k):
         nu.close()
 
 
+def two(k):
+    """the round-2 machinery: coefficient slabs + reservation, the stream-ordered copy, the wave FFT,
+    deferred / ping-pong block schedules with outputs still owed when the engine is destroyed"""
+    rng = np.random.default_rng(1000 + k)
+    L = int(rng.choice([4096, 8192]))
+    rs = int(rng.choice([4, 8]))
+    sched = k % 3
+    os.environ["BFHIP_COEFF_STREAM"] = "2"
+    os.environ["BFHIP_MAC_TARGET_WGS"] = "32" if L == 8192 else "16"
+    if sched == 0:
+        os.environ["BFHIP_OVERLAP"] = "0"
+    elif sched == 1:
+        os.environ["BFHIP_OVERLAP"] = "1"
+    try:
+        e = bf.Engine(L, 2, rs, 8, 8)
+        e.set_interleaved(0, "S24_4LE")
+        e.set_interleaved(1, "S24_4LE")
+        e.reserve_coeffs(16 * 2 * 2 * L * rs)          # room for a quarter of the sets: the rest spills
+        dt = np.float32 if rs == 4 else np.float64
+        for o in range(8):
+            for i in range(8):
+                h = (rng.standard_normal(2 * L) / 400).astype(dt)
+                e.add_filter(in_ch=[i], out_ch=[o], coeff=e.add_coeff(h))
+        e.finalize()
+    finally:
+        for v in ("BFHIP_COEFF_STREAM", "BFHIP_MAC_TARGET_WGS", "BFHIP_OVERLAP"):
+            os.environ.pop(v, None)
+    x = torch.from_numpy((rng.standard_normal((L, 8)) * 1e5).astype(np.int32)).cuda()
+    y = torch.zeros(L, 8, dtype=torch.int32, device="cuda")
+    for _ in range(4):
+        e.block_dev(x, y)
+    e.update_coeff_block(3, 1, (rng.standard_normal(L) / 400).astype(dt))
+    e.set_coeff(5, 9)
+    e.block_dev(x, y)
+    if k & 1:
+        assert e.sync() == 0
+    e.close()                                           # with outputs still owed on the even turns
+    del x, y
+
+
 def main():
     for k in range(20):
         one(k)
+        two(k)
     base = free_mib()
     marks = []
     for k in range(20, 320):
         one(k)
+        if k % 4 == 0:
+            two(k)
         if k % 100 == 19:
             marks.append(free_mib())
     print("free MiB after warm-up %.1f, then %s -> drift %.1f MiB over 300 engines" % (base, ["%.1f" % m for m in marks], base - marks[-1]))
