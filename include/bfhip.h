@@ -16,14 +16,16 @@
  *      mutex snapshot and barriers and calls bfhip_engine_block().
  *
  *  (2) bfhip_convolver.h: the 22 link-time symbols of convolver.h with the reference's
- *      host-memory semantics, executed on the device, for everything that is called
- *      outside the per-block loop (bfconf.c, delay.c, bflogic_eq).
+ *      host-memory semantics.  The per-block ones run on the device (the unfused fallback of a
+ *      host whose modules hook the per-buffer events); the ones the host calls BEFORE it forks
+ *      its processes or from module processes (bfconf.c, delay.c, bflogic_eq) are pure host
+ *      code: HIP state does not survive fork().
  *
  * Error convention follows the host: functions return 0 / a non-negative index
  * on success and a negative BFHIP_E* code on failure; bfhip_last_error() gives the text.
  * Nothing here calls exit(); the patched caller decides (bf_exit(BF_EXIT_OTHER)).
- * If no HIP device / code object is usable every entry point fails with BFHIP_ENODEV:
- * there is no CPU fallback.
+ * If no HIP device / code object is usable every block entry point fails with BFHIP_ENODEV:
+ * there is no CPU fallback for the per-block work.
  */
 #ifndef BFHIP_H
 #define BFHIP_H
@@ -84,8 +86,9 @@ const char *bfhip_version(void);
    (power of two, 4..1048576: up to 8192 the transforms run in LDS, above as multi-kernel
    sequences over global memory; the reference's stock `filter_length: 65536` is covered),
    n_blocks = N partitions per filter, realsize 4 or 8.
-   Device initialisation happens here, lazily on first use of the process: call it in the
-   forked filter process, never in the parent. */
+   The device is initialised here: call it in the forked filter process, never in the parent
+   (nothing the parent needs -- convolver_init, convolver_coeffs2cbuf, ... -- touches
+   the device). */
 bfhip_engine *bfhip_engine_create(int device, int length, int n_blocks, int realsize,
                                   int n_in, int n_out);
 void bfhip_engine_destroy(bfhip_engine *e);
@@ -205,12 +208,13 @@ int bfhip_engine_set_fscale(bfhip_engine *e, int filter, int index, double scale
 int bfhip_engine_block(bfhip_engine *e, const void *rawin, void *rawout,
                        bfhip_overflow overflow[]);
 
-/* Device-resident raw buffers, asynchronous (ordering contract: below).  For small crossbars (coefficient stream under
-   ~100 us per block) the three kernels of a block are queued on three engine-owned streams so
-   that the input FFT of the next block and the inverse FFT of the previous one run beside the
-   MAC, the way the reference overlaps its input, filter and output processes; for large ones
-   (the headline config) the plain sequence on one stream is faster.  BFHIP_OVERLAP=0/1 in the
-   environment forces either. */
+/* Device-resident raw buffers, asynchronous (ordering contract: below).  How the kernels of a
+   block are scheduled is decided at finalize (bfhip_engine_block_mode): small crossbars
+   (coefficient stream under ~100 us per block) overlap the transforms of neighbouring blocks with
+   the MAC on engine-owned side streams, the way the reference overlaps its input, filter and
+   output processes; large ones (the headline config) fuse the inverse transforms of a block with
+   the forward transforms of the next into one launch on one stream.  BFHIP_OVERLAP=0/1 in the
+   environment moves the automatic choice; bfhip_engine_set_overlap decides it. */
 int bfhip_engine_block_dev(bfhip_engine *e, const void *rawin_dev, void *rawout_dev);
 /* ORDERING CONTRACT of bfhip_engine_block_dev.  The engine launches on streams of its own (K1 of
    a pipelined block even on a side stream that does NOT follow the stream given to

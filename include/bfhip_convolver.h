@@ -6,15 +6,20 @@
  *
  * Every buffer is caller-owned HOST memory in the reference's layouts (time domain: 2L reals;
  * halfcomplex from time2freq; "4 re / 4 im" reordered cbufs everywhere else -- SURVEY A.2/A.3).
- * Each call stages its operands to the device, runs the HIP kernel(s) and copies the result
- * back: correct and self-contained, but PCIe-bound -- the per-block loop must use the fused
- * API of bfhip.h instead.  These entry points serve the callers outside that
- * loop: bfconf.c (init, cbufsize, coeffs2cbuf, verify), delay.c (td_*), bflogic_eq
- * (runtime_coeffs2cbuf, fftplan), "processed" coefficient files, debug dumps.
  *
- * convolver_init() only records its arguments: it runs in the parent before fork()
- * (bfconf.c:2786) and HIP state does not survive fork(); the device is initialised lazily by
- * the first call that needs it, per process.
+ * Two kinds of entry points (csrc/convolver_abi.hip and csrc/host_ops.cpp):
+ *   - the per-block ops (raw2cbuf, time2freq, mixnscale, convolve*, dirac*, crossfade, eval,
+ *     freq2time, cbuf2raw, td_convolve) stage their operands to the device, run the HIP
+ *     kernel(s) and copy the result back: correct and self-contained, but PCIe-bound -- the
+ *     per-block loop should use the fused API of bfhip.h instead; they are the
+ *     unfused fallback (e.g. for hosts whose modules hook the per-buffer events);
+ *   - what the host calls in the PARENT before it forks (bfconf.c: init, cbufsize, coeffs2cbuf,
+ *     verify; delay.c: td_new) or from module processes (bflogic_eq: runtime_coeffs2cbuf,
+ *     fftplan) and the debug dump are pure host code (a small host FFT where the reference runs
+ *     FFTW outside its block loop): HIP state does not survive fork(), and a module process has
+ *     no business owning a GPU context.  The device is initialised by the first per-block op, in
+ *     the process that makes it; a per-block op in a fork()ed child of such a process fails with
+ *     fatal code 106.
  *
  * The arithmetic of the FFT-free ops (mixnscale, convolve*, dirac, raw2cbuf, cbuf2raw) is
  * done without FMA contraction in the reference's operation order: results are bit-identical
