@@ -60,3 +60,29 @@ def test_committed_patch_is_what_the_generator_produces(tmp_path):
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert open(PATCH).read() == before
+
+
+def test_every_convolver_symbol_the_host_objects_need_is_exported(tmp_path):
+    """the drop-in claim at link level: compile the reference's host files that reach the convolver
+    (the patched bfrun.c, bfconf.c, delay.c, dai.c, dither.c, firwindow.c) to objects in a temporary
+    directory and check that every `convolver_*` / `bfhip_*` symbol they leave undefined is a
+    dynamic export of libbfhip.so -- the library stands where fftw_convolver.o + convolver_xmm.o
+    stood (reference Makefile:43-44).  (The whole binary cannot be linked here: the configuration
+    lexer needs flex.)"""
+    work = _apply(tmp_path)
+    objs = []
+    for name, extra in (("bfrun.c", ["-DBF_HAVE_BFHIP", "-I" + os.path.join(ROOT, "include")]),
+                        ("bfconf.c", []), ("delay.c", []), ("dai.c", []), ("dither.c", []), ("firwindow.c", [])):
+        src = str(work / name) if name == "bfrun.c" else os.path.join(REF, name)
+        obj = str(tmp_path / (name[:-2] + ".o"))
+        r = subprocess.run(["gcc", "-c", "-O0", "-w", "-I" + REF] + extra + [src, "-o", obj],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, name + ": " + r.stderr[-1500:]
+        objs.append(obj)
+    undef = subprocess.run(["nm", "-u"] + objs, capture_output=True, text=True).stdout.split()
+    need = sorted({s for s in undef if s.startswith(("convolver_", "bfhip_"))})
+    assert len(need) >= 40, need                        # the 21 convolver.h symbols the host uses + the fused API
+    import brutefir_amd as bf
+    dyn = subprocess.run(["nm", "-D", "--defined-only", bf.LIB_PATH], capture_output=True, text=True).stdout.split()
+    missing = [s for s in need if s not in dyn]
+    assert not missing, missing

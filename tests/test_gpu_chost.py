@@ -86,3 +86,41 @@ def test_c_host_with_rccl_reduce_scatter(hip):
     line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["status_bits"] == 0
     assert line["max_abs_output"] > 1000 and line["max_abs_difference_vs_block_dev"] == 0
+
+
+def test_c_host_three_processes_hot_swap(hip, tmp_path):
+    """examples/bfhotswap.c: BruteFIR's process topology from plain C -- the parent prepares the
+    coefficients (host code, never initialises HIP) and forks; the forked FILTER process owns the
+    GPU; a forked MODULE process rewrites one partition in shared memory the way bflogic_eq does;
+    the filter process picks it up at its next block.  Output against the oracle."""
+    exe = os.path.join(ROOT, "examples", "bfhotswap")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "bfhotswap.c"), "-o", exe,
+                           "-L" + os.path.join(ROOT, "brutefir_amd"), "-lbfhip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "brutefir_amd")])
+    L, N, nblk, sw = 1024, 4, 11, 6
+    rng = np.random.default_rng(77)
+    h0 = cases.make_ir(rng, L * N, 1).astype(np.float32)
+    part = cases.make_ir(rng, L, 1).astype(np.float32)
+    x = (rng.standard_normal(nblk * L) * 0.1).astype(np.float32)
+    h0.tofile(tmp_path / "taps0.f32")
+    part.tofile(tmp_path / "part.f32")
+    x.tofile(tmp_path / "in.f32")
+    r = subprocess.run([exe, str(L), str(N), str(nblk), str(sw), str(tmp_path / "taps0.f32"),
+                        str(tmp_path / "part.f32"), str(tmp_path / "in.f32"), str(tmp_path / "out.f32")],
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr
+    assert "replaced from block %d" % sw in r.stderr
+    got = np.fromfile(tmp_path / "out.f32", np.float32).reshape(nblk, L)
+    oe = bo.Engine(L, N, 4, 1, 1)
+    oe.set_interleaved(0, "FLOAT_LE")
+    oe.set_interleaved(1, "FLOAT_LE")
+    h1 = h0.copy()
+    h1[L:2 * L] = part
+    c0, c1 = oe.add_coeff(h0), oe.add_coeff(h1)
+    oe.add_filter(in_ch=[0], out_ch=[0], coeff=c0)
+    for b in range(nblk):
+        if b == sw:
+            oe.set_coeff(0, c1)
+        _, o = oe.block(x[b * L:(b + 1) * L].reshape(L, 1))
+        assert cases.rel_rms(got[b], np.frombuffer(o.tobytes(), np.float32)) <= 1e-5, b
