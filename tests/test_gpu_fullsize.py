@@ -84,6 +84,25 @@ def test_spot_check_two_outputs_against_oracle(full_engine, hip):
             assert err <= 1e-5, (b, err)
     ab = ge.algorithmic_bytes()
     assert ab["mac"] == 65536.0 * (131072 + 2048 + 64)        # C*(F*P + U*P + O)
+    # this IS the headline configuration: the code path bench.py times is the one checked here --
+    # wave FFT, stream-ordered coefficients, deferred output
+    assert ge.uses_wave_fft and ge.uses_stream_layout and ge.block_mode == 2
+    # ... including the device-buffer entry point with its fused [K3 of t-1 | K1 of t] launch: three
+    # more blocks through bfhip_engine_block_dev, outputs owed until the next call / the sync
+    torch = _torch()
+    dev = torch.device("cuda", 0)
+    more = cases.raw_blocks(4321, 3, L, I, FMT)
+    srcs = [torch.from_numpy(b).to(dev) for b in more]
+    outs_dev = [torch.zeros(L, O, dtype=torch.float32, device=dev) for _ in more]
+    torch.cuda.synchronize()
+    for k in range(len(more)):
+        ge.block_dev(srcs[k], outs_dev[k])
+    assert ge.sync() == 0
+    for k, blk in enumerate(more):
+        _, o = oe.block(blk)
+        gy = outs_dev[k].cpu().numpy()[:, outs]
+        oy = np.frombuffer(o.tobytes(), np.float32).reshape(L, len(outs))
+        assert cases.rel_rms(gy, oy) <= 1e-5, k
 
 
 def test_linearity_at_full_size(full_engine):
