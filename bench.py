@@ -403,7 +403,20 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     ranks_seen = [0]
-    if world > 1:
+    # BFHIP_BENCH_REHEARSE_RCCL=1 (with BFHIP_BENCH_REHEARSE_RANKS=N, one GPU): the rehearsal's slice
+    # copy becomes a real RCCL reduce-scatter on a ONE-rank communicator -- process-group set-up,
+    # device barrier, the asynchronous work handle and RCCL's own stream are then the calls and the
+    # ordering of the N > 1 run; only the peers are missing
+    rccl_rehearsal = world == 1 and os.environ.get("BFHIP_BENCH_REHEARSE_RCCL") == "1"
+    if rccl_rehearsal:
+        import socket
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
+        backend = "nccl"
+    if world > 1 or rccl_rehearsal:
         import torch.distributed as dist
         # an RCCL failure is fatal (non-zero exit): never a different transport under this headline
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -474,6 +487,8 @@ def main():
             return True
 
     def start_mixdown(zp, zl):
+        if rehearse > 1 and rccl_rehearsal:
+            return dist.reduce_scatter_tensor(zl, zp[fo:fo + co], async_op=True)   # one-rank communicator
         if rehearse > 1:
             zl.copy_(zp[fo:fo + co])                 # stands in for the reduce-scatter, on the compute stream
             return _Done()
@@ -617,7 +632,9 @@ def main():
         ms = el * 1e3 / args.steps
         value = (co if rehearse > 1 else O) * L * args.steps / el      # rehearsal: this rank's outputs only
         out = {
-            "metric": ("REHEARSAL of one rank of %d (no collective): rank-local samples/sec" % rehearse) if rehearse > 1
+            "metric": ("REHEARSAL of one rank of %d (%s): rank-local samples/sec"
+                       % (rehearse, "RCCL reduce-scatter on a one-rank communicator" if rccl_rehearsal
+                          else "no collective")) if rehearse > 1
                       else (BASELINE_METRIC if args.workload == "C" else "filtered samples/sec"),
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
@@ -663,6 +680,9 @@ def main():
             if eng.block_mode in (2, 3):
                 rf["fft_note"] = "fft_in_ms is the fused [K3 of t-1 | K1 of t] launch; there is no separate K3 launch"
             out["roofline"] = rf
+            if rccl_rehearsal:
+                out["exposed_collective_ms"] = per_rank[0]["exposed_collective_ms"]
+                out["backend"] = "rccl (one-rank communicator)"
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(wl)
         else:
