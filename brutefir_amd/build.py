@@ -19,7 +19,7 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libbfhip.so")
 INC = os.path.join(HERE, "..", "include")
 PUBLIC = [os.path.join("..", "..", "include", h) for h in ("bfhip.h", "bfhip_convolver.h", "bfhip_nupc.h")]
-DEVICE = ["kernels.h", "fft_lds.h", "bigfft.h"] + PUBLIC
+DEVICE = ["kernels.h", "fft_lds.h", "fft_wave.h", "bigfft.h"] + PUBLIC
 # translation unit -> what it includes
 UNITS = {
     "bfhip.hip": DEVICE + ["conv_shared.h"],
