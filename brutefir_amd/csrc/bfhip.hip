@@ -223,10 +223,10 @@ struct bfhip_engine {
     double *d_ps_scale = nullptr;
     std::vector<Coeff> coeffs;
     // Coefficient sets are carved out of a few large slabs instead of one hipMalloc each: the MAC
-    // streams all of them at once (config C: 4096 sets, 8 GiB), and what the address translation
-    // can keep hot depends on how large the physically contiguous pieces are -- thousands of
-    // separate 2 MiB allocations thrash the TLB (measured: the same crossbar with 16 / 32 / 64
-    // partitions per filter ran at 0.84 / 0.81 / 0.79 of peak).
+    // streams all of them at once (config C: 4096 sets, 8 GiB), and thousands of separate 2 MiB
+    // allocations cost it 5-10 % (one hipMalloc per set: 0.79 - 0.86 of peak box to box, one slab
+    // 0.886).  Where inside the slab a set starts matters as much -- the stream-ordered
+    // copy below takes that out of the host's hands.
     struct Slab { void *base = nullptr; size_t cap = 0, used = 0; };
     std::vector<Slab> slabs;
     bool coeff_arena = true;               // BFHIP_COEFF_ARENA=0: one hipMalloc per set
@@ -292,10 +292,6 @@ struct bfhip_engine {
     // K1 / K3 on the wave FFT (fft_wave.h: L = 1024 .. 8192, default from 4096 up; BFHIP_FFT_WAVE=0/1)
     bool wave = false;
     void *d_tww = nullptr;         // its twiddle table
-    // K1/K3 in 256-thread workgroups (L = 8192): slow, but small enough to sit on a CU beside a MAC
-    // workgroup, so that the side streams of the pipelined block do not displace MAC workgroups
-    bool lowfoot = false;          // used for launches that go to the side streams only
-    void *d_tw_lo = nullptr;
 
     // device state
     void *d_tw = nullptr;          // [2L] complex
@@ -593,20 +589,6 @@ void launch_io_wave(bfhip_engine *e, const void *Zp, size_t chunk_stride, int n_
     *err = hipGetLastError();
 }
 
-constexpr int LO_NT = 256;
-
-template <typename T>
-void launch_fft_in_lo(bfhip_engine *e, const uint8_t *raw, int slot, hipError_t *err) {
-    const size_t lds = lds_fft_bytes(13, sizeof(c2<T>));
-    auto k = fft_in_kernel<T, 13, LO_NT>;
-    *err = allow_lds(k, lds);
-    if (*err != hipSuccess) return;
-    hipLaunchKernelGGL(k, dim3(e->n_ch[0]), dim3(LO_NT), lds, e->ls, raw, e->d_fmt[0],
-                       (T *)e->d_prev, (c2<T> *)e->d_ring, (const c2<T> *)e->d_tw_lo, e->R, slot,
-                       (const BlockState *)e->bs_arg, ps_arg(e));
-    *err = hipGetLastError();
-}
-
 template <typename T, int LOG2L>
 void launch_coeff_prep(bfhip_engine *e, const void *taps, int n_taps, double scale, void *H,
                        int n_blocks, hipError_t *err) {
@@ -655,22 +637,6 @@ void launch_ifft_out(bfhip_engine *e, const void *Zp, size_t chunk_stride, int n
                        n_chunks, first, e->d_fmt[1], e->d_over, (const unsigned char *)e->d_skip_quant,
                        raw, e->d_timeout ? (T *)e->d_timeout + (size_t)first * e->L : (T *)nullptr,
                        (const c2<T> *)e->d_tw, e->safety_limit, e->d_status);
-    *err = hipGetLastError();
-    if (*err != hipSuccess) return;
-    launch_dither<T>(e, first, count, raw, err);
-}
-
-template <typename T>
-void launch_ifft_out_lo(bfhip_engine *e, const void *Zp, size_t chunk_stride, int n_chunks,
-                        int first, int count, uint8_t *raw, hipError_t *err) {
-    const size_t lds = lds_fft_bytes(13, sizeof(c2<T>));
-    auto k = ifft_out_kernel<T, 13, LO_NT>;
-    *err = allow_lds(k, lds);
-    if (*err != hipSuccess) return;
-    hipLaunchKernelGGL(k, dim3(count), dim3(LO_NT), lds, e->ls, (const c2<T> *)Zp, chunk_stride,
-                       n_chunks, first, e->d_fmt[1], e->d_over, (const unsigned char *)e->d_skip_quant,
-                       raw, e->d_timeout ? (T *)e->d_timeout + (size_t)first * e->L : (T *)nullptr,
-                       (const c2<T> *)e->d_tw_lo, e->safety_limit, e->d_status);
     *err = hipGetLastError();
     if (*err != hipSuccess) return;
     launch_dither<T>(e, first, count, raw, err);
@@ -1079,7 +1045,7 @@ int build_plan_t(bfhip_engine *e) {
             job.P = P; job.kind = f.coeff < 0 ? TERM_DIRAC : TERM_COEFF;
             job.Y = Yptr(fi);
             filts[e->level[fi]].push_back(job);
-            if (f.coeff >= 0) bytes_H += (double)P * L * sizeof(c2<T>);
+            if (f.coeff >= 0) bytes_H += (double)P * (double)L * (double)sizeof(c2<T>);
             if (fading) {
                 // old-coefficient result for the fade (bfrun.c:1726-1769, 1803-1827)
                 FilterJob<T> old = job;
@@ -1126,7 +1092,7 @@ int build_plan_t(bfhip_engine *e) {
                 tm.H = f.coeff < 0 ? nullptr : (const c2<T> *)e->coeffs[f.coeff].d_H;
                 tm.P = P;
                 tm.scale = (T)(rscale * s_out);
-                if (f.coeff >= 0) bytes_H += (double)P * L * sizeof(c2<T>);
+                if (f.coeff >= 0) bytes_H += (double)P * (double)L * (double)sizeof(c2<T>);
             }
             per_group[g][ei].maxP = std::max(per_group[g][ei].maxP, tm.P);
         }
@@ -1581,7 +1547,6 @@ int do_inputs(bfhip_engine *e, const void *rawin_dev) {
     const int slot = (int)(e->blockcounter % (unsigned int)e->R);
     if (e->big) { int rr = big_reserve(e, (size_t)e->n_ch[0]); if (rr != BFHIP_OK) return rr; }
     if (e->big) DISPATCH_BIG(launch_fft_in_big, e, (const uint8_t *)rawin_dev, slot, &err);
-    else if (e->lowfoot && e->ls != e->stream) DISPATCH_BIG(launch_fft_in_lo, e, (const uint8_t *)rawin_dev, slot, &err);
     else if (e->wave) { DISPATCH_WAVE(launch_fft_in_wave, e, (const uint8_t *)rawin_dev, slot, &err) }
     else DISPATCH(launch_fft_in, e, (const uint8_t *)rawin_dev, slot, &err);
     if (err != hipSuccess) return fail(BFHIP_EHIP, "fft_in launch: %s", hipGetErrorString(err));
@@ -1630,7 +1595,6 @@ int do_outputs(bfhip_engine *e, const void *Zp, size_t chunk_stride, int n_chunk
     }
     if (e->big) { int rr = big_reserve(e, (size_t)count); if (rr != BFHIP_OK) return rr; }
     if (e->big) DISPATCH_BIG(launch_ifft_out_big, e, Zp, chunk_stride, n_chunks, first, count, (uint8_t *)rawout_dev, &err);
-    else if (e->lowfoot && e->ls != e->stream) DISPATCH_BIG(launch_ifft_out_lo, e, Zp, chunk_stride, n_chunks, first, count, (uint8_t *)rawout_dev, &err);
     else if (e->wave) {
         DISPATCH_WAVE(launch_ifft_out_wave, e, Zp, chunk_stride, n_chunks, first, count, (uint8_t *)rawout_dev, &err)
         if (err == hipSuccess) {
@@ -1823,10 +1787,10 @@ void sd_make_filter(std::vector<T> &f, int half, double offset, double beta) {
     double step = 1.0 / ((double)max + offset);
     if (offset == 0.0) max -= 1;
     int n = 0;
-    for (; n <= max; n++) { const double y = kaiser(-1.0 + (double)n * step); f[n] *= y; f[n] *= y; }
+    for (; n <= max; n++) { const double y = kaiser(-1.0 + (double)n * step); f[n] = (T)(f[n] * y); f[n] = (T)(f[n] * y); }
     if (offset == 0.0) max += 1;
     step = 1.0 / ((double)(len - max - 1) - offset);
-    for (; n < len; n++) { const double y = kaiser(((double)(n - max) - offset) * step); f[n] *= y; f[n] *= y; }
+    for (; n < len; n++) { const double y = kaiser(((double)(n - max) - offset) * step); f[n] = (T)(f[n] * y); f[n] = (T)(f[n] * y); }
 }
 
 int subdelay_setup(bfhip_engine *e) {
@@ -1989,7 +1953,7 @@ void bfhip_engine_destroy(bfhip_engine *e) {
                     e->d_bad, e->d_Zp, e->d_entries, e->d_chunks, e->d_rawin, e->d_rawout, e->d_taps,
                     e->d_fring, e->d_Y, e->d_Yold, e->d_evalprev, e->d_jobs,
                     e->d_dither_ch, e->d_dither_state, e->d_dither_table, e->d_randmap, e->d_skip_quant, e->d_timeout,
-                    e->d_big[0], e->d_big[1], e->d_big[2], e->d_tw13, e->d_tw_lo, e->d_tww,
+                    e->d_big[0], e->d_big[1], e->d_big[2], e->d_tw13, e->d_tww,
                     e->d_ps_flags, e->d_ps_live, e->d_ps_scale, e->d_ps_acc, e->d_stream, e->d_where};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto ev : e->ev) (void)hipEventDestroy(ev);
@@ -2373,6 +2337,10 @@ int bfhip_engine_add_filter(bfhip_engine *e,
     if (!e) return fail(BFHIP_EINVAL, "null engine");
     if (e->finalized) return fail(BFHIP_ESTATE, "add_filter after finalize");
     if (n_in_ch < 0 || n_in_f < 0 || n_out_ch < 0) return fail(BFHIP_EINVAL, "add_filter: negative count");
+    if ((n_in_ch > 0 && (!in_ch || !in_scale)) || (n_in_f > 0 && (!in_f || !in_fscale)) ||
+        (n_out_ch > 0 && (!out_ch || !out_scale)))
+        return fail(BFHIP_EINVAL, "add_filter: null array");
+    if (coeff < -1) return fail(BFHIP_EINVAL, "add_filter: coeff %d (-1 = none)", coeff);
     Filter f;
     for (int i = 0; i < n_in_ch; i++) {
         if (in_ch[i] < 0 || in_ch[i] >= e->n_ch[0]) return fail(BFHIP_EINVAL, "add_filter: input channel %d", in_ch[i]);
@@ -2406,27 +2374,22 @@ int bfhip_engine_finalize(bfhip_engine *e) {
         for (auto &f : e->filters) {
             if (f.coeff < 0) continue;
             const int d = clamp_delay(e, f.delayblocks);
-            bytes += (double)cblocks_of(e, f.coeff, d) * e->L * e->csize() * std::max<size_t>(1, f.out_ch.size());
+            bytes += (double)cblocks_of(e, f.coeff, d) * (double)e->L * (double)e->csize() * (double)std::max<size_t>(1, f.out_ch.size());
         }
         // ... and only while the transforms leave most CUs to the MAC: with hundreds of channels the
         // FFT workgroups fill the chip themselves (config D, 256 + 256: 0.178 ms piped, 0.168 plain)
         e->pipelined = bytes / 6.4e12 < 100e-6 && e->n_ch[0] + e->n_ch[1] <= 128;
-        // (BFHIP_OVERLAP=2: pipeline a long MAC at L = 8192 too, with K1/K3 in 256-thread workgroups
-        // that fit on a CU next to a MAC workgroup -- 224 + 288 VGPRs per lane -- so that the side
-        // streams displace nothing.  Measured on config C: the transforms disappear behind the MAC
-        // but the MAC itself slows by 0.5-1.7 %; 1.364 -> 1.344 ms on one box, 1.414 -> 1.419 on
-        // another.  Not the default.  With the 1024-thread kernels on the side streams the MAC's
-        // workgroups used to be pushed together on fewer CUs: 1.74 ms.)
-        if (e->overlap_mode >= 0) { e->pipelined = e->overlap_mode != 0; e->lowfoot = e->lowfoot && e->pipelined; }
+        // (Beside a long MAC the transforms only get in the way: a MAC workgroup takes 320 of a SIMD's
+        // 512 registers per lane, no transform workgroup fits on the same CU, and on a side stream
+        // they either wait for the MAC's tail or push its workgroups together on fewer CUs --
+        // config C 1.40 -> 1.74 ms.  A 256-thread variant that did fit next to round 1's MAC hid
+        // them but slowed the MAC by as much)
+        if (e->overlap_mode >= 0) e->pipelined = e->overlap_mode != 0;
         // (the environment only moves the AUTOMATIC choice: an explicit bfhip_engine_set_overlap wins --
         // the non-uniform convolver depends on its segment engines running strictly in order)
-        if (const char *env = e->overlap_mode < 0 ? getenv("BFHIP_OVERLAP") : nullptr) {       // 0 off, 1 on (full-size kernels), 2 on (narrow kernels)
-            e->pipelined = atoi(env) != 0;
-            e->lowfoot = atoi(env) == 2 && e->log2L == 13 && e->rs == 4;
-        }
+        if (const char *env = e->overlap_mode < 0 ? getenv("BFHIP_OVERLAP") : nullptr) e->pipelined = atoi(env) != 0;
         for (int io = 0; io < 2; io++) for (int c : e->n_vpp[io]) if (c > 1) e->pipelined = false;   // one job table per side
         if (e->big) e->pipelined = false;          // one FFT scratch
-        if (!e->pipelined) e->lowfoot = false;
         // one stream and a MAC that fills the chip for a long time: fuse the output pass of a block
         // with the input pass of the next one (deferred output).  Needs the plain 1:1 raw path.
         bool plain = e->wave && !e->big && e->sdf_length <= 0 && e->dither_channels.empty();
@@ -2436,13 +2399,8 @@ int bfhip_engine_finalize(bfhip_engine *e) {
         // the non-uniform convolver relies on it for its segment engines)
         if (const char *env = getenv("BFHIP_DEFER")) e->defer_out = atoi(env) != 0 && !e->pipelined && plain && e->overlap_mode != 0;
         // small MACs with the wave FFT: the two-stream ping-pong instead of three streams
-        e->pipe2 = e->pipelined && plain && !e->lowfoot;
+        e->pipe2 = e->pipelined && plain;
         if (const char *env = getenv("BFHIP_PIPE2")) e->pipe2 = e->pipe2 && atoi(env) != 0;
-    }
-    if (e->lowfoot) {
-        const std::vector<unsigned char> twlo = make_twiddle_table(13, e->rs, LO_NT);
-        HIPCHK(hipMalloc(&e->d_tw_lo, twlo.size()));
-        HIPCHK(hipMemcpy(e->d_tw_lo, twlo.data(), twlo.size(), hipMemcpyHostToDevice));
     }
     e->R = e->pipelined ? e->N + 1 : e->N;
     // the MAC addresses a ring / a coefficient set with 32-bit byte offsets from its base

@@ -237,10 +237,6 @@ big_out_post(const c2<T> *__restrict__ zout, int first_channel, const DevFormat 
              uint8_t *__restrict__ raw, T *__restrict__ timeout, int L, double safety_limit,
              int *__restrict__ status) {
     constexpr int NT = 1024;
-    __shared__ unsigned int red_n[16];
-    __shared__ int32_t red_i[16];
-    __shared__ double red_l[16];
-    __shared__ int red_s[16];
     const int zi = blockIdx.x, tid = threadIdx.x, ch = first_channel + zi;
     const c2<T> *s = zout + (size_t)zi * L;
     const DevFormat f = fmt[ch];
@@ -248,15 +244,8 @@ big_out_post(const c2<T> *__restrict__ zout, int first_channel, const DevFormat 
     const bool quant = skip_quant == nullptr || !skip_quant[ch];
     uint8_t *base = raw + f.byte_offset;
     const size_t stride = (size_t)f.sample_spacing * f.bytes;
-    const int bits = f.sbytes << 3;
-    const int32_t imin = (int32_t)(-((uint64_t)1 << (bits - 1)));
-    const int32_t imax = (int32_t)(((uint64_t)1 << (bits - 1)) - 1);
-    const double rmin_i = (double)(T)imin, rmax_i = (double)(T)imax;
-    const T rmin_f = (T)(-of.max), rmax_f = (T)of.max;
-    unsigned int n_over = 0;
-    int32_t intlargest = of.intlargest;
-    double largest = of.largest;
-    int st = 0;
+    Quantiser<T> qz;
+    qz.init(f, of, safety_limit);
     for (int n = tid; n < L / 2; n += NT) {
         const c2<T> zz = s[n];
         T xs[2] = {zz.x, zz.y};
@@ -266,61 +255,13 @@ big_out_post(const c2<T> *__restrict__ zout, int first_channel, const DevFormat 
         }
         if (!quant) continue;
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const T x = xs[q];
-            uint8_t *p = base + (size_t)(2 * n + q) * stride;
-            uint8_t tb[8];
-            if (!isfinite(x)) { st |= 1; continue; }
-            if (safety_limit != 0.0 && ((double)x < -safety_limit * of.max || (double)x > safety_limit * of.max)) {
-                st |= 2; continue;
-            }
-            if (f.isfloat) {
-                if (x < (T)0) {
-                    if (x < rmin_f) n_over++;
-                    if ((double)x < -largest) largest = -(double)x;
-                } else {
-                    if (x > rmax_f) n_over++;
-                    if ((double)x > largest) largest = (double)x;
-                }
-                if (f.bytes == 4) {
-                    const uint32_t u = __float_as_uint((float)x);
-                    tb[0] = u & 0xff; tb[1] = (u >> 8) & 0xff; tb[2] = (u >> 16) & 0xff; tb[3] = u >> 24;
-                } else {
-                    const uint64_t u = (uint64_t)__double_as_longlong((double)x);
-#pragma unroll
-                    for (int i = 0; i < 8; i++) tb[i] = (u >> (8 * i)) & 0xff;
-                }
-            } else {
-                const int32_t v = real2int_no_dither((double)x, rmin_i, rmax_i, imin, imax, n_over, intlargest, largest);
-                const uint32_t u = (uint32_t)v;
-                tb[0] = u & 0xff; tb[1] = (u >> 8) & 0xff; tb[2] = (u >> 16) & 0xff; tb[3] = u >> 24;
-            }
-            store_raw_bytes(p, tb, f.bytes, f.swap);
-        }
+        for (int q = 0; q < 2; q++) qz.put(xs[q], base + (size_t)(2 * n + q) * stride);
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        n_over += __shfl_down(n_over, off);
-        const int32_t oi = __shfl_down(intlargest, off);
-        intlargest = oi > intlargest ? oi : intlargest;
-        const double ol = __shfl_down(largest, off);
-        largest = ol > largest ? ol : largest;
-        st |= __shfl_down(st, off);
-    }
-    const int wave = tid >> 6, lane = tid & 63;
-    if (lane == 0) { red_n[wave] = n_over; red_i[wave] = intlargest; red_l[wave] = largest; red_s[wave] = st; }
-    __syncthreads();
+    qz.reduce(tid, NT);
     if (tid == 0 && quant) {
-        for (int w = 1; w < NT / 64; w++) {
-            n_over += red_n[w];
-            intlargest = red_i[w] > intlargest ? red_i[w] : intlargest;
-            largest = red_l[w] > largest ? red_l[w] : largest;
-            st |= red_s[w];
-        }
-        over[ch].n_overflows = of.n_overflows + n_over;
-        over[ch].intlargest = intlargest;
-        over[ch].largest = largest;
-        if (st) atomicOr(status, st);
+        qz.commit(of);
+        over[ch] = of;
+        if (qz.st) atomicOr(status, qz.st);
     }
 }
 

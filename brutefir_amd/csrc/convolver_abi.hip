@@ -223,70 +223,18 @@ template <typename T>
 __global__ __launch_bounds__(256) void
 k_real2raw(const T *real, uint8_t *raw, DevFormat f, int n_samples, DevOverflow *over,
            double safety_limit, int *status) {
-    __shared__ unsigned int red_n[4];
-    __shared__ int32_t red_i[4];
-    __shared__ double red_l[4];
-    __shared__ int red_s[4];
     const int tid = threadIdx.x;
     DevOverflow of = *over;
-    const int bits = f.sbytes << 3;
-    const int32_t imin = (int32_t)(-((uint64_t)1 << (bits - 1)));
-    const int32_t imax = (int32_t)(((uint64_t)1 << (bits - 1)) - 1);
-    const double rmin_i = (double)(T)imin, rmax_i = (double)(T)imax;
-    const T rmin_f = (T)(-of.max), rmax_f = (T)of.max;
-    unsigned int n_over = 0;
-    int32_t intlargest = of.intlargest;
-    double largest = of.largest;
-    int st = 0;
+    Quantiser<T> qz;
+    qz.init(f, of, safety_limit);
     uint8_t *base = raw + f.byte_offset;
     const size_t stride = (size_t)f.sample_spacing * f.bytes;
-    for (int n = tid; n < n_samples; n += 256) {
-        const T x = real[n];
-        uint8_t tb[8];
-        if (!isfinite(x)) { st |= 1; continue; }
-        if (safety_limit != 0.0 && ((double)x < -safety_limit * of.max || (double)x > safety_limit * of.max)) { st |= 2; continue; }
-        if (f.isfloat) {
-            if (x < (T)0) {
-                if (x < rmin_f) n_over++;
-                if ((double)x < -largest) largest = -(double)x;
-            } else {
-                if (x > rmax_f) n_over++;
-                if ((double)x > largest) largest = (double)x;
-            }
-            if (f.bytes == 4) {
-                const uint32_t u = __float_as_uint((float)x);
-                tb[0] = u & 0xff; tb[1] = (u >> 8) & 0xff; tb[2] = (u >> 16) & 0xff; tb[3] = u >> 24;
-            } else {
-                const uint64_t u = (uint64_t)__double_as_longlong((double)x);
-                for (int i = 0; i < 8; i++) tb[i] = (u >> (8 * i)) & 0xff;
-            }
-        } else {
-            const uint32_t u = (uint32_t)real2int_no_dither((double)x, rmin_i, rmax_i, imin, imax, n_over, intlargest, largest);
-            tb[0] = u & 0xff; tb[1] = (u >> 8) & 0xff; tb[2] = (u >> 16) & 0xff; tb[3] = u >> 24;
-        }
-        store_raw_bytes(base + (size_t)n * stride, tb, f.bytes, f.swap);
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        n_over += __shfl_down(n_over, off);
-        const int32_t oi = __shfl_down(intlargest, off);
-        intlargest = oi > intlargest ? oi : intlargest;
-        const double ol = __shfl_down(largest, off);
-        largest = ol > largest ? ol : largest;
-        st |= __shfl_down(st, off);
-    }
-    if ((tid & 63) == 0) { red_n[tid >> 6] = n_over; red_i[tid >> 6] = intlargest; red_l[tid >> 6] = largest; red_s[tid >> 6] = st; }
-    __syncthreads();
+    for (int n = tid; n < n_samples; n += 256) qz.put(real[n], base + (size_t)n * stride);
+    qz.reduce(tid, 256);
     if (tid == 0) {
-        for (int w = 1; w < 4; w++) {
-            n_over += red_n[w];
-            intlargest = red_i[w] > intlargest ? red_i[w] : intlargest;
-            largest = red_l[w] > largest ? red_l[w] : largest;
-            st |= red_s[w];
-        }
-        over->n_overflows = of.n_overflows + n_over;
-        over->intlargest = intlargest;
-        over->largest = largest;
-        if (st) atomicOr(status, st);
+        qz.commit(of);
+        *over = of;
+        if (qz.st) atomicOr(status, qz.st);
     }
 }
 
@@ -322,8 +270,7 @@ __global__ void k_real2raw_dither(const T *real, uint8_t *raw, DevFormat f, int 
         }
         s0 = nsub(v, (T)q);
         const uint32_t u = (uint32_t)q;
-        uint8_t tb[4] = {(uint8_t)(u & 0xff), (uint8_t)((u >> 8) & 0xff), (uint8_t)((u >> 16) & 0xff), (uint8_t)(u >> 24)};
-        store_raw_bytes(base + (size_t)n * stride, tb, f.bytes, f.swap);
+        store_raw_word(base + (size_t)n * stride, (uint64_t)u, f.bytes, f.swap);
     }
     fb[0] = s0; fb[1] = s1;
     *over = of;

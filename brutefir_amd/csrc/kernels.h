@@ -169,21 +169,20 @@ __device__ __forceinline__ void load_pairs_words(const uint8_t *__restrict__ bas
     for (int i = 0; i < QP; i++) cur[i] = mk<T>(word_to_real<T>(w0[i], f), word_to_real<T>(w1[i], f));
 }
 
-// t[] holds the sample's bytes in little-endian order
-__device__ __forceinline__ void store_raw_bytes(uint8_t *p, const uint8_t *t, int bytes, int swap) {
+// w holds the sample's bytes, little end first
+__device__ __forceinline__ void store_raw_word(uint8_t *p, uint64_t w, int bytes, int swap) {
     const uintptr_t a = (uintptr_t)p;
     if (bytes == 4 && (a & 3) == 0) {
-        uint32_t u = (uint32_t)t[0] | (uint32_t)t[1] << 8 | (uint32_t)t[2] << 16 | (uint32_t)t[3] << 24;
+        uint32_t u = (uint32_t)w;
         if (swap) u = __builtin_bswap32(u);
         *reinterpret_cast<uint32_t *>(p) = u;
     } else if (bytes == 2 && (a & 1) == 0) {
-        uint16_t u = (uint16_t)((uint32_t)t[0] | (uint32_t)t[1] << 8);
+        uint16_t u = (uint16_t)w;
         if (swap) u = __builtin_bswap16(u);
         *reinterpret_cast<uint16_t *>(p) = u;
-    } else if (swap) {
-        for (int i = 0; i < bytes; i++) p[i] = t[bytes - 1 - i];
     } else {
-        for (int i = 0; i < bytes; i++) p[i] = t[i];
+        if (swap) w = __builtin_bswap64(w) >> (8 * (8 - bytes));
+        for (int i = 0; i < bytes; i++) p[i] = (uint8_t)(w >> (8 * i));
     }
 }
 
@@ -1211,6 +1210,85 @@ real2int_no_dither(double v, double rmin, double rmax, int32_t imin, int32_t ima
     return s;
 }
 
+// One output channel's requantiser without dither, the way convolver_cbuf2raw drives it
+// (fftw_convolver.c:482-518, real2raw.h:24-250): NaN and safety-limit screening, clipping with the
+// overflow bookkeeping of struct bfoverflow, the store in the channel's sample format.  Every
+// thread keeps its own counters; reduce() leaves the workgroup's totals with thread 0.
+template <typename T> struct Quantiser {
+    DevFormat f;
+    double of_max, safety, rmin_i, rmax_i, largest;
+    int32_t imin, imax, intlargest;
+    T rmin_f, rmax_f;
+    unsigned int n_over;
+    int st;
+
+    __device__ __forceinline__ void init(const DevFormat &fmt, const DevOverflow &of, double safety_limit) {
+        f = fmt; of_max = of.max; safety = safety_limit;
+        const int bits = f.sbytes << 3;
+        imin = (int32_t)(-((uint64_t)1 << (bits - 1)));
+        imax = (int32_t)(((uint64_t)1 << (bits - 1)) - 1);
+        rmin_i = (double)(T)imin; rmax_i = (double)(T)imax;
+        rmin_f = (T)(-of.max); rmax_f = (T)of.max;
+        n_over = 0; intlargest = of.intlargest; largest = of.largest; st = 0;
+    }
+    // false: the sample is left unwritten and a status bit says why (bfrun.c:1925-1935)
+    __device__ __forceinline__ bool screen(T x) {
+        if (!isfinite(x)) { st |= 1; return false; }
+        if (safety != 0.0 && ((double)x < -safety * of_max || (double)x > safety * of_max)) { st |= 2; return false; }
+        return true;
+    }
+    __device__ __forceinline__ int32_t to_int(T x) {
+        return real2int_no_dither((double)x, rmin_i, rmax_i, imin, imax, n_over, intlargest, largest);
+    }
+    // the sample's bytes, little end first
+    __device__ __forceinline__ uint64_t encode(T x) {
+        if (!f.isfloat) return (uint64_t)(uint32_t)to_int(x);
+        if (x < (T)0) {
+            if (x < rmin_f) n_over++;
+            if ((double)x < -largest) largest = -(double)x;
+        } else {
+            if (x > rmax_f) n_over++;
+            if ((double)x > largest) largest = (double)x;
+        }
+        return f.bytes == 4 ? (uint64_t)__float_as_uint((float)x) : (uint64_t)__double_as_longlong((double)x);
+    }
+    __device__ __forceinline__ void put(T x, uint8_t *p) {
+        if (screen(x)) store_raw_word(p, encode(x), f.bytes, f.swap);
+    }
+    // workgroup totals (a count, two maxima, status bits: order independent) into thread 0; every
+    // thread of the workgroup (at most 1024) has to call it
+    __device__ __forceinline__ void reduce(int tid, int n_threads) {
+        __shared__ unsigned int red_n[16];
+        __shared__ int32_t red_i[16];
+        __shared__ double red_l[16];
+        __shared__ int red_s[16];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            n_over += __shfl_down(n_over, off);
+            const int32_t oi = __shfl_down(intlargest, off);
+            intlargest = oi > intlargest ? oi : intlargest;
+            const double ol = __shfl_down(largest, off);
+            largest = ol > largest ? ol : largest;
+            st |= __shfl_down(st, off);
+        }
+        const int wave = tid >> 6;
+        if ((tid & 63) == 0) { red_n[wave] = n_over; red_i[wave] = intlargest; red_l[wave] = largest; red_s[wave] = st; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < (n_threads + 63) / 64; w++) {
+                n_over += red_n[w];
+                intlargest = red_i[w] > intlargest ? red_i[w] : intlargest;
+                largest = red_l[w] > largest ? red_l[w] : largest;
+                st |= red_s[w];
+            }
+        }
+    }
+    // thread 0 after reduce(): fold the block's totals into the channel's struct
+    __device__ __forceinline__ void commit(DevOverflow &of) const {
+        of.n_overflows += n_over; of.intlargest = intlargest; of.largest = largest;
+    }
+};
+
 // One workgroup per output channel: sum the chunk partials, build Z' = E + iO, inverse
 // complex FFT; samples x[2n], x[2n+1] = Re, Im z[n]; the first L samples are the block's
 // output (fftw_convolver.c:493-515).  Then cbuf2raw: finite / safety tests, quantise or
@@ -1228,9 +1306,6 @@ ifft_out_body(int zi /* index into Zp's channel axis */, unsigned char *smem,
     constexpr int L = 1 << LOG2L, NT = NTP;
     constexpr int QU = UT<T, LOG2L, NT>::QU;
     LdsArr<T> s{reinterpret_cast<c2<T> *>(smem)};
-    __shared__ unsigned int red_n[16];
-    __shared__ int32_t red_i[16];
-    __shared__ double red_l[16];
     const int tid = threadIdx.x;
     const int ch = first_channel + zi;         // output channel
     const c2<T> *z = Zp + (size_t)zi * L;
@@ -1298,15 +1373,8 @@ ifft_out_body(int zi /* index into Zp's channel axis */, unsigned char *smem,
 
     uint8_t *base = raw + f.byte_offset;
     const size_t stride = (size_t)f.sample_spacing * f.bytes;
-    const int bits = f.sbytes << 3;
-    const int32_t imin = (int32_t)(-((uint64_t)1 << (bits - 1)));
-    const int32_t imax = (int32_t)(((uint64_t)1 << (bits - 1)) - 1);
-    const double rmin_i = (double)(T)imin, rmax_i = (double)(T)imax;
-    const T rmin_f = (T)(-of.max), rmax_f = (T)of.max;
-    unsigned int n_over = 0;
-    int32_t intlargest = of.intlargest;
-    double largest = of.largest;
-    int st = 0;
+    Quantiser<T> qz;
+    qz.init(f, of, safety_limit);
 
     for (int n = tid; n < L / 2; n += NT) {
         const c2<T> zz = s[n];
@@ -1317,65 +1385,14 @@ ifft_out_body(int zi /* index into Zp's channel axis */, unsigned char *smem,
         }
         if (!quant) continue;
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const T x = xs[q];
-            uint8_t *p = base + (size_t)(2 * n + q) * stride;
-            uint8_t tb[8];
-            if (!isfinite(x)) { st |= 1; continue; }
-            if (safety_limit != 0.0 && ((double)x < -safety_limit * of.max || (double)x > safety_limit * of.max)) {
-                st |= 2; continue;
-            }
-            if (f.isfloat) {
-                if (x < (T)0) {
-                    if (x < rmin_f) n_over++;
-                    if ((double)x < -largest) largest = -(double)x;
-                } else {
-                    if (x > rmax_f) n_over++;
-                    if ((double)x > largest) largest = (double)x;
-                }
-                if (f.bytes == 4) {
-                    const uint32_t u = __float_as_uint((float)x);
-                    tb[0] = u & 0xff; tb[1] = (u >> 8) & 0xff; tb[2] = (u >> 16) & 0xff; tb[3] = u >> 24;
-                } else {
-                    const uint64_t u = (uint64_t)__double_as_longlong((double)x);
-#pragma unroll
-                    for (int i = 0; i < 8; i++) tb[i] = (u >> (8 * i)) & 0xff;
-                }
-            } else {
-                const int32_t v = real2int_no_dither((double)x, rmin_i, rmax_i, imin, imax,
-                                                     n_over, intlargest, largest);
-                const uint32_t u = (uint32_t)v;
-                tb[0] = u & 0xff; tb[1] = (u >> 8) & 0xff; tb[2] = (u >> 16) & 0xff; tb[3] = u >> 24;
-            }
-            store_raw_bytes(p, tb, f.bytes, f.swap);
-        }
+        for (int q = 0; q < 2; q++) qz.put(xs[q], base + (size_t)(2 * n + q) * stride);
     }
 
-    // workgroup reduction of the overflow bookkeeping (order independent: count, max, max)
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        n_over += __shfl_down(n_over, off);
-        const int32_t oi = __shfl_down(intlargest, off);
-        intlargest = oi > intlargest ? oi : intlargest;
-        const double ol = __shfl_down(largest, off);
-        largest = ol > largest ? ol : largest;
-        st |= __shfl_down(st, off);
-    }
-    const int wave = tid >> 6, lane = tid & 63;
-    __shared__ int red_s[16];
-    if (lane == 0) { red_n[wave] = n_over; red_i[wave] = intlargest; red_l[wave] = largest; red_s[wave] = st; }
-    __syncthreads();
+    qz.reduce(tid, NT);
     if (tid == 0 && quant) {
-        for (int w = 1; w < NT / 64; w++) {
-            n_over += red_n[w];
-            intlargest = red_i[w] > intlargest ? red_i[w] : intlargest;
-            largest = red_l[w] > largest ? red_l[w] : largest;
-            st |= red_s[w];
-        }
-        over[ch].n_overflows = of.n_overflows + n_over;
-        over[ch].intlargest = intlargest;
-        over[ch].largest = largest;
-        if (st) atomicOr(status, st);
+        qz.commit(of);
+        over[ch] = of;
+        if (qz.st) atomicOr(status, qz.st);
     }
 }
 
@@ -1501,15 +1518,8 @@ ifft_out_wave_body(int zi /* index into Zp's channel axis */, unsigned char *sme
 
     uint8_t *base = raw + f.byte_offset;
     const size_t stride = (size_t)f.sample_spacing * f.bytes;
-    const int bits = f.sbytes << 3;
-    const int32_t imin = (int32_t)(-((uint64_t)1 << (bits - 1)));
-    const int32_t imax = (int32_t)(((uint64_t)1 << (bits - 1)) - 1);
-    const double rmin_i = (double)(T)imin, rmax_i = (double)(T)imax;
-    const T rmin_f = (T)(-of.max), rmax_f = (T)of.max;
-    unsigned int n_over = 0;
-    int32_t intlargest = of.intlargest;
-    double largest = of.largest;
-    int st = 0;
+    Quantiser<T> qz;
+    qz.init(f, of, safety_limit);
 
     // the common raw layout -- integer samples in naturally aligned 32-bit words (S24_4LE, S32_LE,
     // their byte-swapped twins) -- is decided once for the channel: no byte assembly per sample
@@ -1530,41 +1540,12 @@ ifft_out_wave_body(int zi /* index into Zp's channel axis */, unsigned char *sme
         for (int q = 0; q < 2; q++) {
             const T x = xs[q];
             uint8_t *p = base + (o0 + (q ? stride32 : 0u));
-            if (!isfinite(x)) { st |= 1; continue; }
-            if (safety_limit != 0.0 && ((double)x < -safety_limit * of.max || (double)x > safety_limit * of.max)) {
-                st |= 2; continue;
-            }
             if (word32) {
-                uint32_t u = (uint32_t)real2int_no_dither((double)x, rmin_i, rmax_i, imin, imax,
-                                                          n_over, intlargest, largest);
+                if (!qz.screen(x)) continue;
+                uint32_t u = (uint32_t)qz.to_int(x);
                 if (f.swap) u = __builtin_bswap32(u);
                 *reinterpret_cast<uint32_t *>(p) = u;
-                continue;
-            }
-            uint8_t tb[8];
-            if (f.isfloat) {
-                if (x < (T)0) {
-                    if (x < rmin_f) n_over++;
-                    if ((double)x < -largest) largest = -(double)x;
-                } else {
-                    if (x > rmax_f) n_over++;
-                    if ((double)x > largest) largest = (double)x;
-                }
-                if (f.bytes == 4) {
-                    const uint32_t u = __float_as_uint((float)x);
-                    tb[0] = u & 0xff; tb[1] = (u >> 8) & 0xff; tb[2] = (u >> 16) & 0xff; tb[3] = u >> 24;
-                } else {
-                    const uint64_t u = (uint64_t)__double_as_longlong((double)x);
-#pragma unroll
-                    for (int i = 0; i < 8; i++) tb[i] = (u >> (8 * i)) & 0xff;
-                }
-            } else {
-                const int32_t v = real2int_no_dither((double)x, rmin_i, rmax_i, imin, imax,
-                                                     n_over, intlargest, largest);
-                const uint32_t u = (uint32_t)v;
-                tb[0] = u & 0xff; tb[1] = (u >> 8) & 0xff; tb[2] = (u >> 16) & 0xff; tb[3] = u >> 24;
-            }
-            store_raw_bytes(p, tb, f.bytes, f.swap);
+            } else qz.put(x, p);
         }
     }
 
@@ -1573,10 +1554,10 @@ ifft_out_wave_body(int zi /* index into Zp's channel axis */, unsigned char *sme
     // reduces its own share in registers and its first lane folds it into the channel's struct
     // with atomics -- no LDS, no barrier behind the stores, and in the steady state (peaks already
     // recorded, nothing clipped) no memory operation at all.
-    n_over = (unsigned int)wave_all_i32((int)n_over, [](int a, int b) { return a + b; });
-    intlargest = wave_all_i32(intlargest, [](int a, int b) { return a > b ? a : b; });
-    largest = wave_max_f64(largest);
-    st = wave_all_i32(st, [](int a, int b) { return a | b; });
+    const unsigned int n_over = (unsigned int)wave_all_i32((int)qz.n_over, [](int a, int b) { return a + b; });
+    const int32_t intlargest = wave_all_i32(qz.intlargest, [](int a, int b) { return a > b ? a : b; });
+    const double largest = wave_max_f64(qz.largest);
+    const int st = wave_all_i32(qz.st, [](int a, int b) { return a | b; });
     if ((tid & 63) == 0 && quant) {
         if (n_over) atomicAdd(&over[ch].n_overflows, n_over);
         if (intlargest > of.intlargest) atomicMax(&over[ch].intlargest, intlargest);
@@ -1716,10 +1697,6 @@ vchan_out_kernel(const VOutJob *__restrict__ jobs, const VOutMember *__restrict_
                  const ByteOp *__restrict__ ops, T *__restrict__ samples /* [n_out][L] */,
                  const DevFormat *__restrict__ fmt, DevOverflow *__restrict__ over,
                  uint8_t *__restrict__ raw, int L, double safety_limit, int *__restrict__ status) {
-    __shared__ unsigned int red_n[4];
-    __shared__ int32_t red_i[4];
-    __shared__ double red_l[4];
-    __shared__ int red_s[4];
     const VOutJob job = jobs[blockIdx.x];
     const VOutMember *mem = members + job.first_member;
     const int tid = threadIdx.x;
@@ -1730,15 +1707,8 @@ vchan_out_kernel(const VOutJob *__restrict__ jobs, const VOutMember *__restrict_
     DevOverflow of = over[last];
     uint8_t *base = raw + f.byte_offset;
     const size_t stride = (size_t)f.sample_spacing * f.bytes;
-    const int bits = f.sbytes << 3;
-    const int32_t imin = (int32_t)(-((uint64_t)1 << (bits - 1)));
-    const int32_t imax = (int32_t)(((uint64_t)1 << (bits - 1)) - 1);
-    const double rmin_i = (double)(T)imin, rmax_i = (double)(T)imax;
-    const T rmin_f = (T)(-of.max), rmax_f = (T)of.max;
-    unsigned int n_over = 0;
-    int32_t intlargest = of.intlargest;
-    double largest = of.largest;
-    int st = 0;
+    Quantiser<T> qz;
+    qz.init(f, of, safety_limit);
     for (int n = tid; n < L; n += 256) {
         T x = (T)0;
         bool filled = false;
@@ -1748,51 +1718,14 @@ vchan_out_kernel(const VOutJob *__restrict__ jobs, const VOutMember *__restrict_
             x = filled ? x + v : v;
             filled = true;
         }
-        uint8_t tb[8];
         if (job.dither) { samples[(size_t)job.fmt_channel * L + n] = x; continue; }     // tests + quantiser: dither_kernel
-        if (!isfinite(x)) { st |= 1; continue; }
-        if (safety_limit != 0.0 && ((double)x < -safety_limit * of.max || (double)x > safety_limit * of.max)) { st |= 2; continue; }
-        if (f.isfloat) {
-            if (x < (T)0) {
-                if (x < rmin_f) n_over++;
-                if ((double)x < -largest) largest = -(double)x;
-            } else {
-                if (x > rmax_f) n_over++;
-                if ((double)x > largest) largest = (double)x;
-            }
-            if (f.bytes == 4) {
-                const uint32_t u = __float_as_uint((float)x);
-                tb[0] = u & 0xff; tb[1] = (u >> 8) & 0xff; tb[2] = (u >> 16) & 0xff; tb[3] = u >> 24;
-            } else {
-                const uint64_t u = (uint64_t)__double_as_longlong((double)x);
-                for (int i = 0; i < 8; i++) tb[i] = (u >> (8 * i)) & 0xff;
-            }
-        } else {
-            const uint32_t u = (uint32_t)real2int_no_dither((double)x, rmin_i, rmax_i, imin, imax, n_over, intlargest, largest);
-            tb[0] = u & 0xff; tb[1] = (u >> 8) & 0xff; tb[2] = (u >> 16) & 0xff; tb[3] = u >> 24;
-        }
-        store_raw_bytes(base + (size_t)n * stride, tb, f.bytes, f.swap);
+        qz.put(x, base + (size_t)n * stride);
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        n_over += __shfl_down(n_over, off);
-        const int32_t oi = __shfl_down(intlargest, off);
-        intlargest = oi > intlargest ? oi : intlargest;
-        const double ol = __shfl_down(largest, off);
-        largest = ol > largest ? ol : largest;
-        st |= __shfl_down(st, off);
-    }
-    if ((tid & 63) == 0) { red_n[tid >> 6] = n_over; red_i[tid >> 6] = intlargest; red_l[tid >> 6] = largest; red_s[tid >> 6] = st; }
-    __syncthreads();
+    qz.reduce(tid, 256);
     if (tid == 0) {
-        for (int w = 1; w < 4; w++) {
-            n_over += red_n[w];
-            intlargest = red_i[w] > intlargest ? red_i[w] : intlargest;
-            largest = red_l[w] > largest ? red_l[w] : largest;
-            st |= red_s[w];
-        }
-        of.n_overflows += n_over; of.intlargest = intlargest; of.largest = largest;
+        qz.commit(of);
         if (!job.dither) for (int m = 0; m < job.n_members; m++) over[mem[m].channel] = of;     // bfrun.c:1999-2001
-        if (st) atomicOr(status, st);
+        if (qz.st) atomicOr(status, qz.st);
     }
 }
 
@@ -1966,8 +1899,7 @@ dither_kernel(const T *__restrict__ samples,          // [n_out][L] from ifft_ou
         }
         if (!skip) {
             const uint32_t u = (uint32_t)myq;
-            uint8_t tb[4] = {(uint8_t)(u & 0xff), (uint8_t)((u >> 8) & 0xff), (uint8_t)((u >> 16) & 0xff), (uint8_t)(u >> 24)};
-            store_raw_bytes(base + (size_t)n * stride, tb, f.bytes, f.swap);
+            store_raw_word(base + (size_t)n * stride, (uint64_t)u, f.bytes, f.swap);
         }
     }
     for (int off = 32; off > 0; off >>= 1) flags |= __shfl_down(flags, off);
