@@ -124,6 +124,8 @@ def lib():
     L.bfhip_engine_blockcounter.argtypes = [vp]
     L.bfhip_engine_ring_depth.argtypes = [vp]
     L.bfhip_engine_block_mode.argtypes = [vp]
+    L.bfhip_engine_output_lag.argtypes = [vp]
+    L.bfhip_engine_flush.argtypes = [vp]
     L.bfhip_engine_uses_wave_fft.argtypes = [vp]
     L.bfhip_engine_uses_stream_layout.argtypes = [vp]
     L.bfhip_engine_enable_timing.argtypes = [vp, ci]
@@ -378,6 +380,15 @@ class Engine:
 
     def sync(self):
         return _check(lib().bfhip_engine_sync(self.h))
+
+    def flush(self):
+        """launch the output passes still owed (deferred / ping-pong schedule); does not wait"""
+        _check(lib().bfhip_engine_flush(self.h))
+
+    @property
+    def output_lag(self):
+        """block calls that pass before a block's output pass is launched (0, 1 or 2)"""
+        return lib().bfhip_engine_output_lag(self.h)
 
     def inputs_dev(self, rawin_dev):
         _check(lib().bfhip_engine_inputs_dev(self.h, _ptr(rawin_dev)))

@@ -1359,6 +1359,7 @@ int do_outputs(bfhip_engine *e, const void *Zp, size_t chunk_stride, int n_chunk
 // the inverse transforms of the blocks whose output is still owed (deferred output: one, ping-pong
 // schedule: up to two), oldest first, each as a launch of its own
 int flush_pending(bfhip_engine *e) {
+    const bool side = e->pipe2 && !e->pendq.empty();
     while (!e->pendq.empty()) {
         const bfhip_engine::Pending p = e->pendq.front();
         e->pendq.pop_front();
@@ -1371,6 +1372,12 @@ int flush_pending(bfhip_engine *e) {
         if (p.out_done) HIPCHK(hipEventRecord(p.out_done, e->ls));
     }
     e->ls = e->stream;
+    if (side) {
+        // whatever the main stream does next (a phase call's MAC writes the partial-sum buffer these
+        // output passes read) comes behind them
+        HIPCHK(hipEventRecord(e->ev_io[0], e->s_in));
+        HIPCHK(hipStreamWaitEvent(e->stream, e->ev_io[0], 0));
+    }
     return BFHIP_OK;
 }
 
@@ -2856,6 +2863,17 @@ static int block_dev_impl(bfhip_engine *e, const void *rawin_dev, void *rawout_d
     e->ls = e->stream;
     advance(e);
     return BFHIP_OK;
+}
+
+int bfhip_engine_flush(bfhip_engine *e) {
+    if (!e || !e->finalized) return fail(BFHIP_ESTATE, "engine not finalized");
+    HIPCHK(hipSetDevice(e->device));
+    return flush_pending(e);
+}
+
+int bfhip_engine_output_lag(const bfhip_engine *e) {
+    if (!e || !e->finalized) return 0;
+    return e->pipe2 ? 2 : ((e->defer_out && !e->pipelined) ? 1 : 0);
 }
 
 int bfhip_engine_sync(bfhip_engine *e) {

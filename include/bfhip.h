@@ -232,9 +232,20 @@ int bfhip_engine_block_dev(bfhip_engine *e, const void *rawin_dev, void *rawout_
    its producer of rawin_dev -- the input transform waits for it, nothing else does, so the
    overlap of neighbouring blocks is kept; out_done_event (hipEvent_t, may be NULL) is recorded by
    the engine behind the last kernel of THIS block: after it rawout_dev is complete and
-   rawin_dev may be reused. */
+   rawin_dev may be reused.
+   WHEN it is recorded: by the call that launches the block's output pass -- the call itself, or,
+   where outputs are owed, the call bfhip_engine_output_lag() blocks later (1: deferred output,
+   2: ping-pong), or bfhip_engine_flush / bfhip_engine_sync, whichever comes first.  Until then the
+   event still carries whatever was recorded on it before: a caller must not wait on the event
+   of block t before call t + lag (or flush, or sync) has returned. */
 int bfhip_engine_block_dev_ev(bfhip_engine *e, const void *rawin_dev, void *rawout_dev,
                               void *in_ready_event, void *out_done_event);
+/* how many later block calls pass before a block's output pass is launched (0, 1 or 2; fixed at
+   finalize, see bfhip_engine_block_mode) */
+int bfhip_engine_output_lag(const bfhip_engine *e);
+/* launch the output passes still owed now (and record their out_done events); does not wait.
+   The schedule picks up again with the next block call. */
+int bfhip_engine_flush(bfhip_engine *e);
 /* wait for the stream; returns accumulated status bits (and clears them) or an error */
 int bfhip_engine_sync(bfhip_engine *e);
 

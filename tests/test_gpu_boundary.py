@@ -284,7 +284,8 @@ def test_block_dev_ev_orders_an_asynchronous_producer_and_consumer(hip, L):
     for overlap in (1, 0):
         e = build(overlap)
         assert e.block_mode == ((3 if L >= 4096 else 1) if overlap else 0)
-        owed = 2 if e.block_mode == 3 else 0              # the ping-pong schedule writes block k during call k+2
+        owed = e.output_lag                               # the ping-pong schedule writes block k during call k+2
+        assert owed == (2 if e.block_mode == 3 else 0)
         side = torch.cuda.Stream()
         pinned = [torch.from_numpy(b).pin_memory() for b in blocks]
         rawin = torch.zeros(L, I, dtype=torch.int32, device=dev)          # ONE buffer, reused
@@ -398,6 +399,73 @@ def test_deferred_output_gives_the_same_samples(hip, monkeypatch):
     got = [t.cpu().numpy() for t in keep]
     where = [[j for j in range(len(blocks)) if np.array_equal(got[k], want[j])] for k in range(len(blocks))]
     assert where == [[k] for k in range(len(blocks))], str(where)
+
+
+@pytest.mark.parametrize("schedule", ["deferred", "pingpong"])
+def test_flush_launches_owed_outputs_without_waiting(hip, monkeypatch, schedule):
+    """bfhip_engine_flush (include/bfhip.h): a caller that wants the samples of the block it just
+    submitted does not wait for later calls -- flush launches the owed output passes and records
+    their `output done` events; the consumer waits on the event, never on the host.  After a flush
+    the schedule starts over; a phase call on the main stream right behind a flushed ping-pong
+    engine (its MAC reuses the partial-sum buffer) stays ordered behind the flushed passes."""
+    import torch
+    L, N, I, O = 4096, 3, 3, 4
+    dev = torch.device("cuda", 0)
+    if schedule == "deferred":
+        monkeypatch.setenv("BFHIP_OVERLAP", "0")
+        monkeypatch.setenv("BFHIP_DEFER", "1")
+    else:
+        monkeypatch.setenv("BFHIP_OVERLAP", "1")
+    e, _ = cases.crossbar(hip.Engine, L, N, 4, I, O, "S24_4LE", "S24_4LE")
+    monkeypatch.delenv("BFHIP_OVERLAP")
+    monkeypatch.delenv("BFHIP_DEFER", raising=False)
+    assert e.output_lag == (1 if schedule == "deferred" else 2) and e.block_mode == (2 if schedule == "deferred" else 3)
+    monkeypatch.setenv("BFHIP_OVERLAP", "0")
+    monkeypatch.setenv("BFHIP_DEFER", "0")
+    plain, _ = cases.crossbar(hip.Engine, L, N, 4, I, O, "S24_4LE", "S24_4LE")
+    monkeypatch.delenv("BFHIP_OVERLAP")
+    monkeypatch.delenv("BFHIP_DEFER")
+    assert plain.output_lag == 0 and plain.block_mode == 0
+    blocks = cases.raw_blocks(77, N + 6, L, I, "S24_4LE")
+    want = [np.frombuffer(plain.block(b)[1].tobytes(), np.int32).reshape(L, O).copy() for b in blocks]
+    srcs = [torch.from_numpy(b).to(dev) for b in blocks]
+    outs = [torch.zeros(L, O, dtype=torch.int32, device=dev) for _ in blocks]
+    keep = [torch.zeros(L, O, dtype=torch.int32, device=dev) for _ in blocks]
+    side = torch.cuda.Stream()
+    done = [torch.cuda.Event() for _ in blocks]
+    for ev in done:
+        ev.record(side)
+    torch.cuda.synchronize()
+    z = torch.zeros(O, L, 2, dtype=torch.float32, device=dev)
+    with torch.cuda.stream(side):
+        for k in range(len(blocks)):
+            e.block_dev_ev(srcs[k], outs[k], None, done[k].cuda_event)
+            if k % 3 == 2:                                # every third block is wanted at once
+                e.flush()
+                for j in range(k - 2, k + 1):
+                    side.wait_event(done[j])
+                    keep[j].copy_(outs[j], non_blocking=True)
+        e.flush()
+        for j in range(len(blocks) - len(blocks) % 3, len(blocks)):
+            side.wait_event(done[j])
+            keep[j].copy_(outs[j], non_blocking=True)
+    torch.cuda.synchronize()
+    for k in range(len(blocks)):
+        assert np.array_equal(keep[k].cpu().numpy(), want[k]), (schedule, k)
+    # a phase call straight behind a flush: same spectra as the plain engine's for the next block
+    e.block_dev(srcs[0], outs[0])
+    e.block_dev(srcs[1], outs[1])
+    e.flush()
+    e.inputs_dev(srcs[2])
+    e.mac_dev(z)
+    e.advance()
+    for k in range(3):
+        plain.inputs_dev(srcs[k])
+        zp = torch.zeros_like(z)
+        plain.mac_dev(zp)
+        plain.advance()
+    assert e.sync() == 0 and plain.sync() == 0
+    assert np.array_equal(z.cpu().numpy(), zp.cpu().numpy())
 
 
 @pytest.mark.parametrize("L", [1024, 2048])
