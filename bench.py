@@ -93,7 +93,14 @@ def _cpu_worker(args):
         for i in range(I):
             c = e.add_coeff(np.roll(h, 17 * (o * I + i)))
             e.add_filter(in_ch=[i], out_ch=[o], coeff=c)
-    raw = (rng.standard_normal((L, I)) * 0.1 * 8388608).astype(np.int32)
+    x = rng.standard_normal((L, I)) * 0.1
+    if fmt == "S24_4LE":
+        raw = (x * 8388608).astype(np.int32)
+    elif fmt == "FLOAT64_LE":
+        raw = x.astype(np.float64)
+    else:
+        raise SystemExit("bench.py: no CPU-baseline input generator for raw format %s" % fmt)
+    assert raw.nbytes == L * I * bo.SAMPLE_FORMATS[fmt][0]
     # like the reference (bfrun.c:1745) the oracle only reaches back over blocks that exist:
     # fill the ring first so that every timed block does all N partitions
     for _ in range(N):
