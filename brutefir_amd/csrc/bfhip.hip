@@ -1382,6 +1382,7 @@ int flush_pending(bfhip_engine *e) {
 }
 
 int ensure_ready(bfhip_engine *e) {
+    if (!e) return fail(BFHIP_EINVAL, "null engine");
     if (!e->finalized) return fail(BFHIP_ESTATE, "engine not finalized");
     HIPCHK(hipSetDevice(e->device));
     if (e->plan_dirty && !e->pendq.empty()) {
@@ -2653,6 +2654,7 @@ int bfhip_engine_set_fscale(bfhip_engine *e, int filter, int index, double scale
 int bfhip_engine_inputs_dev(bfhip_engine *e, const void *rawin_dev) {
     int r = ensure_ready(e);
     if (r != BFHIP_OK) return r;
+    if (!rawin_dev) return fail(BFHIP_EINVAL, "inputs: null buffer");
     if ((r = flush_pending(e)) != BFHIP_OK) return r;
     e->ls = e->stream;
     timing_begin(e);
@@ -2664,6 +2666,7 @@ int bfhip_engine_inputs_dev(bfhip_engine *e, const void *rawin_dev) {
 int bfhip_engine_mac_dev(bfhip_engine *e, void *z_dev) {
     int r = ensure_ready(e);
     if (r != BFHIP_OK) return r;
+    if (!z_dev) return fail(BFHIP_EINVAL, "mac: null buffer");
     if ((r = flush_pending(e)) != BFHIP_OK) return r;      // an output owed by bfhip_engine_block_dev goes first
     e->ls = e->stream;
     timing_begin(e);
@@ -2687,6 +2690,7 @@ int bfhip_engine_outputs_dev(bfhip_engine *e, const void *z_dev, int first, int 
     if (r != BFHIP_OK) return r;
     if ((r = flush_pending(e)) != BFHIP_OK) return r;      // an output owed by bfhip_engine_block_dev goes first
     if (first < 0 || count < 0 || first + count > e->n_ch[1]) return fail(BFHIP_EINVAL, "outputs: channel range");
+    if (!z_dev || !rawout_dev) return fail(BFHIP_EINVAL, "outputs: null buffer");
     e->ls = e->stream;
     timing_begin(e);
     if ((r = record(e, 4)) != BFHIP_OK) return r;
@@ -2700,6 +2704,7 @@ int bfhip_engine_outputs_inputs_dev(bfhip_engine *e, const void *z_dev, int firs
     if (r != BFHIP_OK) return r;
     if ((r = flush_pending(e)) != BFHIP_OK) return r;      // an output owed by bfhip_engine_block_dev goes first
     if (first < 0 || count < 0 || first + count > e->n_ch[1]) return fail(BFHIP_EINVAL, "outputs: channel range");
+    if (!z_dev || !rawout_dev || !rawin_dev) return fail(BFHIP_EINVAL, "outputs_inputs: null buffer");
     if (!e->dither_channels.empty() || e->has_vchan || count == 0 || e->big) {
         // the dither pass follows the inverse transforms: keep the two launches apart
         if ((r = bfhip_engine_outputs_dev(e, z_dev, first, count, rawout_dev)) != BFHIP_OK) return r;
@@ -2738,6 +2743,7 @@ static int block_dev_impl(bfhip_engine *e, const void *rawin_dev, void *rawout_d
                           hipEvent_t in_ready, hipEvent_t out_done) {
     int r = ensure_ready(e);
     if (r != BFHIP_OK) return r;
+    if (!rawin_dev || !rawout_dev) return fail(BFHIP_EINVAL, "block_dev: null buffer");
     const bool pipe = e->pipelined;
     const int buf = (int)(e->blocks_done & 1);
     void *Zp = ((pipe || e->defer_out) && buf) ? e->d_Zp2 : e->d_Zp;
@@ -3187,6 +3193,7 @@ int bfhip_engine_get_timing(bfhip_engine *e, double ms[4]) {
 int bfhip_engine_algorithmic_bytes(bfhip_engine *e, double bytes[2]) {
     int r = ensure_ready(e);
     if (r != BFHIP_OK) return r;
+    if (!bytes) return fail(BFHIP_EINVAL, "algorithmic_bytes: null array");
     bytes[0] = e->alg_bytes_total;
     bytes[1] = e->alg_bytes_mac;
     return BFHIP_OK;

@@ -356,6 +356,7 @@ extern "C" {
 // one I/O block of L_0 frames, device-resident raw buffers, asynchronous on the nupc's stream
 int bfhip_nupc_block_dev(bfhip_nupc *n, const void *rawin_dev, void *rawout_dev) {
     if (!n || !n->finalized) return nfail(BFHIP_ESTATE, "nupc not finalized");
+    if (!rawin_dev || !rawout_dev) return nfail(BFHIP_EINVAL, "nupc_block_dev: null buffer");
     NCHK(hipSetDevice(n->device));
     const int L0 = n->seg[0].L;
     const unsigned long long end = (n->block + 1) * (unsigned long long)L0;       // samples received

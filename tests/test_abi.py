@@ -124,3 +124,21 @@ def test_host_delay_machine_matches_delay_c_without_a_device():
             assert np.array_equal(a, c), (seed, b, F, ss, maxd, init, delay)
         L.bfhip_selftest_delay_free(d)
         O.bfo_delay_free(o)
+
+
+def test_no_entry_point_crashes_on_a_null_handle():
+    """tests/helpers/null_sweep.py in a child process (a crash must not take pytest with it): all
+    bfhip_engine_* / bfhip_nupc_* calls with a NULL handle return an error or a neutral 0"""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "null_sweep.py")],
+                       capture_output=True, text=True, timeout=300)
+    lines = r.stdout.strip().splitlines()
+    assert r.returncode == 0 and lines and lines[-1] == "SWEEP DONE", (r.returncode, lines[-3:], r.stderr[-1000:])
+    calls = dict(ln.split() for ln in lines[:-1])
+    assert len(calls) >= 70
+    neutral = {"bfhip_engine_output_lag", "bfhip_engine_blockcounter", "bfhip_engine_uses_wave_fft",
+               "bfhip_engine_uses_stream_layout", "bfhip_engine_ring_depth", "bfhip_nupc_taps", "bfhip_nupc_latency"}
+    for name, ret in calls.items():
+        if ret == "void":
+            continue
+        assert (int(ret) == 0) if name in neutral else (int(ret) < 0), (name, ret)

@@ -1,0 +1,136 @@
+"""GPU: a LIVE engine handed bad arguments -- null buffers, indices out of range, calls in the wrong
+state.  Every one must come back as an error code with a message (never a crash, never a kernel
+launched on a null pointer: a faulting kernel can take the whole node down), and the engine must
+still compute the right samples afterwards."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import bforacle as bo
+import cases
+
+pytestmark = pytest.mark.gpu
+L, N, I, O = 256, 2, 2, 2
+
+
+def test_bad_arguments_are_errors_and_leave_the_engine_usable(hip):
+    lib = hip.lib()
+    null = C.c_void_p(0)
+    e = hip.Engine(L, N, 4, I, O)
+    h = e.h
+    fmt = hip.make_format("S24_4LE", I, 0)
+
+    def bad(rc, text=None):
+        assert rc < 0, rc
+        msg = lib.bfhip_last_error().decode()
+        assert msg and (text is None or text in msg), msg
+
+    # ---- before finalize
+    bad(lib.bfhip_engine_set_format(h, 2, 0, C.byref(fmt)))
+    bad(lib.bfhip_engine_set_format(h, 0, I, C.byref(fmt)))
+    bad(lib.bfhip_engine_set_format(h, 0, 0, None))
+    bad(lib.bfhip_engine_map_channels(h, 0, 0, (C.c_int * I)(0, 0)))
+    bad(lib.bfhip_engine_map_channels(h, 0, 1, None))
+    bad(lib.bfhip_engine_set_delay(h, 0, -1, 0))
+    bad(lib.bfhip_engine_set_delay(h, 1, O, 0))
+    bad(lib.bfhip_engine_set_delay(h, 0, 0, -5))
+    bad(lib.bfhip_engine_set_subdelay(h, 0, I, 0))
+    bad(lib.bfhip_engine_enable_subdelay(h, 0, 9.0), "half filter length")
+    bad(lib.bfhip_engine_enable_dither(h, None, 1, 48000, 0))
+    bad(lib.bfhip_engine_set_powersave(h, -1.0))
+    bad(lib.bfhip_engine_block_dev(h, null, null), "not finalized")
+    bad(lib.bfhip_engine_sync(h), "not finalized")
+    bad(lib.bfhip_engine_flush(h), "not finalized")
+    taps = np.zeros(L * N, np.float32)
+    taps[3] = 0.5
+    bad(lib.bfhip_engine_add_coeff(h, None, 10, 1.0, 0))
+    bad(lib.bfhip_engine_add_coeff(h, taps.ctypes.data_as(C.c_void_p), -1, 1.0, 0))
+    bad(lib.bfhip_engine_add_coeff(h, taps.ctypes.data_as(C.c_void_p), L * N, 1.0, N + 1), "blocks")
+    bad(lib.bfhip_engine_add_coeff_processed(h, None, 1))
+    bad(lib.bfhip_engine_add_coeff_processed_blocks(h, None, 1, 0))
+    bad(lib.bfhip_engine_add_coeff_processed_blocks(h, (C.c_void_p * 1)(None), 1, 0), "NULL")
+    one, half = (C.c_int * 1)(0), (C.c_double * 1)(1.0)
+    bad(lib.bfhip_engine_add_filter(h, 1, None, half, 0, None, None, 1, one, half, -1, 0, 0), "null array")
+    bad(lib.bfhip_engine_add_filter(h, 1, one, half, 0, None, None, 1, one, None, -1, 0, 0), "null array")
+    bad(lib.bfhip_engine_add_filter(h, 1, (C.c_int * 1)(I), half, 0, None, None, 1, one, half, -1, 0, 0), "input channel")
+    bad(lib.bfhip_engine_add_filter(h, 1, one, half, 0, None, None, 1, (C.c_int * 1)(O), half, -1, 0, 0), "output channel")
+    bad(lib.bfhip_engine_add_filter(h, 1, one, half, 1, one, half, 1, one, half, -1, 0, 0), "not defined yet")
+    bad(lib.bfhip_engine_add_filter(h, 1, one, half, 0, None, None, 1, one, half, 7, 0, 0), "not loaded")
+    bad(lib.bfhip_engine_add_filter(h, 1, one, half, 0, None, None, 1, one, half, -2, 0, 0))
+    bad(lib.bfhip_engine_add_filter(h, -1, one, half, 0, None, None, 1, one, half, -1, 0, 0))
+
+    # ---- a real network: the bad calls above left nothing behind
+    e.set_interleaved(0, "S24_4LE")
+    e.set_interleaved(1, "S24_4LE")
+    oe = bo.Engine(L, N, 4, I, O)
+    oe.set_interleaved(0, "S24_4LE")
+    oe.set_interleaved(1, "S24_4LE")
+    irs = {}
+    for o in range(O):
+        for i in range(I):
+            hh = cases.make_ir(np.random.default_rng(9 + o * I + i), L * N, I)
+            irs[(o, i)] = hh
+            e.add_filter(in_ch=[i], out_ch=[o], coeff=e.add_coeff(hh))
+            oe.add_filter(in_ch=[i], out_ch=[o], coeff=oe.add_coeff(hh))
+    e.finalize()
+
+    # ---- after finalize
+    bad(lib.bfhip_engine_set_format(h, 0, 0, C.byref(fmt)), "after finalize")
+    bad(lib.bfhip_engine_add_filter(h, 1, one, half, 0, None, None, 1, one, half, -1, 0, 0), "after finalize")
+    bad(lib.bfhip_engine_set_overlap(h, 1), "after finalize")
+    bad(lib.bfhip_engine_set_coeff(h, I * O, 0))
+    bad(lib.bfhip_engine_set_coeff(h, 0, I * O + 3))
+    bad(lib.bfhip_engine_set_delayblocks(h, -1, 0))
+    bad(lib.bfhip_engine_set_scale(h, 0, 2, 0, 1.0))
+    bad(lib.bfhip_engine_set_scale(h, 0, 0, 1, 1.0), "bad index")
+    bad(lib.bfhip_engine_set_fscale(h, 0, 0, 1.0), "bad index")
+    bad(lib.bfhip_engine_refresh_coeff_processed(h, 0, N, None))
+    bad(lib.bfhip_engine_refresh_coeff_processed(h, 0, 0, None), "no host buffer")
+    bad(lib.bfhip_engine_update_coeff_block(h, 0, 0, None))
+    bad(lib.bfhip_engine_read_coeff_processed(h, 99, taps.ctypes.data_as(C.c_void_p)))
+    bad(lib.bfhip_engine_block(h, None, None, None), "null buffer")
+    bad(lib.bfhip_engine_block_dev(h, null, null), "null buffer")
+    bad(lib.bfhip_engine_block_dev_ev(h, null, null, None, None), "null buffer")
+    bad(lib.bfhip_engine_inputs_dev(h, null), "null buffer")
+    bad(lib.bfhip_engine_mac_dev(h, null), "null buffer")
+    bad(lib.bfhip_engine_outputs_dev(h, null, 0, O, null), "null buffer")
+    bad(lib.bfhip_engine_outputs_dev(h, null, 1, O, null), "channel range")
+    bad(lib.bfhip_engine_outputs_inputs_dev(h, null, 0, O, null, null), "null buffer")
+    bad(lib.bfhip_engine_get_overflow(h, O, C.byref(hip.Overflow())))
+    bad(lib.bfhip_engine_get_overflow(h, 0, None))
+    bad(lib.bfhip_engine_algorithmic_bytes(h, None), "null array")
+    bad(lib.bfhip_engine_get_timing(h, None))
+    bad(lib.bfhip_engine_read_ring_slot(h, 0, 99, taps.ctypes.data_as(C.c_void_p)))
+    bad(lib.bfhip_engine_read_output_spectrum(h, O, taps.ctypes.data_as(C.c_void_p)))
+    bad(lib.bfhip_engine_rt_submit(h, None), "not in real-time mode")
+    bad(lib.bfhip_engine_rt_wait(h, None, None), "not in real-time mode")
+    bad(lib.bfhip_engine_prewarm(h)) if e.blockcounter else None
+
+    # ---- and the engine still works
+    for blk in cases.raw_blocks(3, N + 2, L, I, "S24_4LE"):
+        st, out = e.block(blk)
+        so, want = oe.block(blk)
+        assert st == so == 0
+        assert np.abs(np.frombuffer(out.tobytes(), np.int32).astype(np.int64) - want.view(np.int32)).max() <= 1
+    bad(lib.bfhip_engine_prewarm(h), "already")
+
+
+def test_nupc_bad_arguments(hip):
+    lib = hip.lib()
+    null = C.c_void_p(0)
+    assert not lib.bfhip_nupc_create(0, 4, 1, 1, 0, None, None)
+    assert not lib.bfhip_nupc_create(0, 4, 1, 1, 2, (C.c_int * 2)(128, 64), (C.c_int * 2)(2, 2))      # descending
+    assert b"ascend" in lib.bfhip_nupc_last_error()
+    n = hip.Nupc([64, 128], [2, 2], 4, 1, 1)
+    assert lib.bfhip_nupc_block_dev(n.h, null, null) < 0                        # not finalized
+    assert lib.bfhip_nupc_add_filter(n.h, 1, 0, None, 10, 1.0, 1.0) < 0
+    n.add_filter(0, 0, np.ones(10, np.float32))
+    n.finalize()
+    assert lib.bfhip_nupc_block_dev(n.h, null, null) < 0
+    assert b"null buffer" in lib.bfhip_nupc_last_error()
+    assert lib.bfhip_nupc_get_overflow(n.h, 1, None) < 0
+    x = np.zeros((64, 1), np.float32)
+    x[0, 0] = 1.0
+    st, out = n.block(x)
+    assert st == 0 and np.allclose(np.frombuffer(out.tobytes(), np.float32)[:10], 1.0, atol=1e-6)
