@@ -45,6 +45,10 @@ int fail(int code, const char *fmt, ...) {
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
     g_err = buf;
+    // a failed runtime call (an allocation that did not fit, say) leaves its code behind as the
+    // "last error"; reported here, it must not be found again by the launch check of a later,
+    // unrelated call
+    (void)hipGetLastError();
     return code;
 }
 
@@ -246,7 +250,7 @@ struct bfhip_engine {
     unsigned long long watch_seq = 0;       // bfhip_coeff_dirty_sequence() at the last poll
     unsigned long long watch_lost = 0;      // bfhip_dirty_lost() at the last poll
     std::vector<Filter> filters;
-    bool finalized = false, plan_dirty = true;
+    bool finalized = false, finalize_failed = false, plan_dirty = true;
     unsigned int blockcounter = 0;
     unsigned long long blocks_done = 0;      // since creation (procblocks analogue)
 
@@ -2368,9 +2372,20 @@ int bfhip_engine_add_filter(bfhip_engine *e,
     return (int)e->filters.size() - 1;
 }
 
+static int finalize_impl(bfhip_engine *e);
+
 int bfhip_engine_finalize(bfhip_engine *e) {
     if (!e) return fail(BFHIP_EINVAL, "null engine");
     if (e->finalized) return BFHIP_OK;
+    // a finalize that failed half way (out of device memory, a bad coefficient set) leaves partial
+    // state behind that only bfhip_engine_destroy cleans up: it is not retried
+    if (e->finalize_failed) return fail(BFHIP_ESTATE, "finalize failed before: destroy this engine");
+    const int r = finalize_impl(e);
+    if (r != BFHIP_OK) { e->finalize_failed = true; e->finalized = false; }
+    return r;
+}
+
+static int finalize_impl(bfhip_engine *e) {
     HIPCHK(hipSetDevice(e->device));
     const size_t L = e->L;
     const size_t prev_b = (size_t)e->n_ch[0] * L * e->rs;

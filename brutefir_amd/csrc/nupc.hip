@@ -90,7 +90,7 @@ nupc_emit_kernel(T *__restrict__ acc, unsigned long long pos, int A, int n_out, 
 
 thread_local std::string n_err;
 
-int nfail(int code, const std::string &msg) { n_err = msg; return code; }
+int nfail(int code, const std::string &msg) { n_err = msg; (void)hipGetLastError(); return code; }   // (clears the sticky runtime error)
 
 #define NCHK(expr)                                                                          \
     do {                                                                                    \

@@ -134,3 +134,30 @@ def test_nupc_bad_arguments(hip):
     x[0, 0] = 1.0
     st, out = n.block(x)
     assert st == 0 and np.allclose(np.frombuffer(out.tobytes(), np.float32)[:10], 1.0, atol=1e-6)
+
+
+def test_a_configuration_that_does_not_fit_the_device_is_an_error_not_a_crash(hip):
+    """256 inputs x 60 000 partitions of 8192 taps: the spectrum rings alone would take 1 TB"""
+    e = hip.Engine(8192, 60000, 4, 256, 1)
+    e.set_interleaved(0, "S24_4LE")
+    e.set_interleaved(1, "S24_4LE")
+    e.add_filter(in_ch=[0], out_ch=[0], coeff=e.add_coeff(np.ones(16, np.float32)))
+    with pytest.raises(hip.BfhipError, match="out of device memory"):
+        e.finalize()
+    with pytest.raises(hip.BfhipError, match="finalize failed before"):      # not retried on half-built state
+        e.finalize()
+    with pytest.raises(hip.BfhipError, match="not finalized"):
+        e.sync()
+    e.close()
+    with pytest.raises(hip.BfhipError, match="exceed 4 GiB"):       # 32-bit offsets inside a coefficient set
+        e2 = hip.Engine(8192, 70000, 4, 1, 1)
+        e2.set_interleaved(0, "S24_4LE")
+        e2.set_interleaved(1, "S24_4LE")
+        e2.add_filter(in_ch=[0], out_ch=[0], coeff=e2.add_coeff(np.ones(16, np.float32)))
+        e2.finalize()
+    # the device is fine afterwards
+    ge, _ = cases.crossbar(hip.Engine, L, N, 4, I, O)
+    oe, _ = cases.crossbar(bo.Engine, L, N, 4, I, O)
+    blk = cases.raw_blocks(5, 1, L, I, "S24_4LE")[0]
+    assert np.abs(np.frombuffer(ge.block(blk)[1].tobytes(), np.int32).astype(np.int64)
+                  - oe.block(blk)[1].view(np.int32)).max() <= 1
