@@ -75,15 +75,27 @@ def test_spot_check_two_outputs_against_oracle(full_engine, hip):
         for i in range(I):
             oe.add_filter(in_ch=[i], out_ch=[k], coeff=oe.add_coeff(spot[(o, i)]))
     blocks = cases.raw_blocks(1234, N + 4, L, I, FMT)
+    got = []
     for b, blk in enumerate(blocks):
         gs, g = ge.block(blk)
         os_, o = oe.block(blk)
         assert gs == os_ == 0
+        gy = np.frombuffer(g.tobytes(), np.float32).reshape(L, O)[:, outs]
+        got.append(gy.copy())
         if b >= N:
-            gy = np.frombuffer(g.tobytes(), np.float32).reshape(L, O)[:, outs]
             oy = np.frombuffer(o.tobytes(), np.float32).reshape(L, len(outs))
             err = cases.rel_rms(gy, oy)
             assert err <= 1e-5, (b, err)
+    # ... and, with nothing from oracle/ involved: the same two outputs as the float64 linear
+    # convolution of the whole stream (scipy / pocketfft), every block from the first
+    from scipy.signal import fftconvolve
+    x = np.concatenate(blocks).astype(np.float64) / 8388608.0
+    got = np.concatenate(got).astype(np.float64)
+    for k, o in enumerate(outs):
+        want = np.zeros(len(x))
+        for i in range(I):
+            want += fftconvolve(x[:, i], spot[(o, i)].astype(np.float64))[:len(x)]
+        assert cases.rel_rms(got[:, k], want) <= 1e-5, o
     ab = ge.algorithmic_bytes()
     assert ab["mac"] == 65536.0 * (131072 + 2048 + 64)        # C*(F*P + U*P + O)
     # this IS the headline configuration: the code path bench.py times is the one checked here --
