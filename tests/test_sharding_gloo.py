@@ -1,6 +1,6 @@
-"""CPU, world_size 2 over gloo: the multi-GPU decomposition (brutefir_amd/sharding.py).
-Each rank owns half of the inputs and computes partial output spectra for ALL outputs; one
-mix-down collective leaves each rank the finished spectra of its half of the outputs.  The
+"""CPU, world_size 2 and 4 over gloo: the multi-GPU decomposition (brutefir_amd/sharding.py).
+Each rank owns its share of the inputs and computes partial output spectra for ALL outputs; one
+mix-down collective leaves each rank the finished spectra of its share of the outputs.  The
 partial spectra are produced by the oracle here (the HIP engine needs a GPU); what is under
 test is the sharding arithmetic and the collective plumbing bench.py uses."""
 import os
@@ -62,12 +62,13 @@ def _worker(rank, world, port, q):
     q.put((rank, worst))
 
 
-def test_input_sharded_crossbar_mixdown_world2():
+@pytest.mark.parametrize("world", [2, 4])
+def test_input_sharded_crossbar_mixdown(world):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
