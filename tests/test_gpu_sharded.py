@@ -177,3 +177,25 @@ def test_bench_refuses_two_ranks_on_one_device_under_the_rccl_headline():
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert "BFHIP_DIST_BACKEND=gloo" in r.stderr
+
+
+def test_bench_step_loop_with_a_real_rccl_reduce_scatter_on_one_rank():
+    """The RCCL calls of the N > 1 step loop -- process-group set-up, device barrier, asynchronous
+    `reduce_scatter_tensor` on RCCL's own stream, the work handle the compute stream waits on, the
+    object all-gather -- executed on THIS device with a one-rank communicator
+    (BFHIP_BENCH_REHEARSE_RCCL=1: rank 0 of 4 reduce-scatters its own slice).  Only the peers are
+    missing; what runs on the driver's 8-GPU node is this code."""
+    import json
+    import subprocess
+    env = dict(os.environ, BFHIP_BENCH_REHEARSE_RANKS="4", BFHIP_BENCH_REHEARSE_RCCL="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BFHIP_DIST_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "6",
+                        "--workload", "B", "--no-cpu-baseline"], capture_output=True, text=True, timeout=280, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["backend"].startswith("rccl") and "RCCL reduce-scatter" in d["metric"]
+    assert d["config"]["status_bits"] == 0 and d["value"] > 0
+    assert d["exposed_collective_ms"] is not None and d["exposed_collective_ms"] >= 0
