@@ -364,6 +364,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--workload", default="C", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the end-to-end check of the timed configuration's outputs (after the timed region)")
     ap.add_argument("--host-io", action="store_true",
                     help="time bfhip_engine_block() with HOST raw buffers (PCIe both ways and a "
                          "sync per block included) -- informative, never the headline value")
@@ -524,8 +526,12 @@ def main():
         _out_p = ctypes.c_void_p(host_out.ctypes.data)
         _in_p = [ctypes.c_void_p(a.ctypes.data) for a in host_in]
 
+    # which device buffers block k reads and writes: the pool and the one output buffer while timing,
+    # per-block buffers during the verification pass (same step loop, same launches)
+    bufs = {"in": lambda k: raw_in[k % n_pool], "out": lambda k: raw_out}
+
     def step(k):
-        src = raw_in[k % n_pool]
+        src = bufs["in"](k)
         if shards == 1:
             if args.host_io:
                 if _lib.bfhip_engine_rt_submit(eng.h, _in_p[k % n_pool]) < 0:
@@ -536,7 +542,7 @@ def main():
                         raise RuntimeError(_lib.bfhip_last_error().decode())
                     host_inflight[0] -= 1
             else:
-                eng.block_dev(src, raw_out)
+                eng.block_dev(src, bufs["out"](k))
             return
         b = k % depth
         if pipelined:
@@ -545,7 +551,7 @@ def main():
             # of block k (both are a handful of workgroups).  Everything is inside the timed
             # region; the pipeline is drained before the clock stops.
             if len(pending) == 2:
-                work, pb = pending.pop(0)
+                work, pb, kb = pending.pop(0)
                 if timed[0] and k % 4 == 0:
                     # how long the compute stream stalls for the collective (= what of it is NOT
                     # hidden behind the previous block's kernels)
@@ -556,18 +562,18 @@ def main():
                     wait_events.append((ea, eb))
                 else:
                     work.wait()
-                eng.outputs_inputs_dev(z_loc[pb], fo, co, raw_out, src)
+                eng.outputs_inputs_dev(z_loc[pb], fo, co, bufs["out"](kb), src)
             else:
                 eng.inputs_dev(src)
             eng.mac_dev(z_part[b])
             eng.advance()
-            pending.append((start_mixdown(z_part[b], z_loc[b]), b))
+            pending.append((start_mixdown(z_part[b], z_loc[b]), b, k))
         else:
             eng.inputs_dev(src)
             eng.mac_dev(z_part[b])
             eng.advance()
             sharding.mixdown(z_part[b], z_loc[b])
-            eng.outputs_dev(z_loc[b], fo, co, raw_out)
+            eng.outputs_dev(z_loc[b], fo, co, bufs["out"](k))
 
     status_acc = [0]
 
@@ -582,9 +588,9 @@ def main():
                 raise RuntimeError(_lib.bfhip_last_error().decode())
             host_inflight[0] -= 1
         while pending:
-            work, pb = pending.pop(0)
+            work, pb, kb = pending.pop(0)
             work.wait()
-            eng.outputs_dev(z_loc[pb], fo, co, raw_out)
+            eng.outputs_dev(z_loc[pb], fo, co, bufs["out"](kb))
 
     def fence():
         torch.cuda.synchronize()
@@ -615,6 +621,72 @@ def main():
     status = eng.sync() | status_acc[0]
     tm = eng.timing()
     src_hash = source_hash()
+    eng.enable_timing(0)
+
+    def verify():
+        """End-to-end check of the very configuration that was just timed, through the same step
+        loop (fused launches, outputs owed for one or two calls, and -- at N > 1 -- the real
+        mix-down collective): N silent blocks empty the rings, ONE block of noise on the first and
+        the last input channel follows (the two ends of the input sharding), then N silent blocks.
+        This rank's outputs over those N + 1 blocks must be the linear convolution of that block
+        with the very impulse responses that were loaded, computed here in float64 with torch.fft."""
+        timed[0] = False
+        k0 = args.warmup + args.steps
+        nb = 2 * N + 1
+        probe = [0] if I == 1 else [0, I - 1]
+        if rehearse > 1:
+            probe = [fi]                  # one rank alone: only its own inputs reach its outputs
+        x = torch.zeros_like(raw_in[0])
+        x[:, probe] = raw_in[0][:, probe]
+        silence = torch.zeros_like(raw_in[0])
+        vout = [torch.zeros_like(raw_out) for _ in range(nb)]
+        bufs["in"] = lambda k: x if k - k0 == N else silence
+        bufs["out"] = lambda k: vout[k - k0]
+        for k in range(k0, k0 + nb):
+            step(k)
+        drain()
+        st = eng.sync()
+        torch.cuda.synchronize()
+        got = torch.cat(vout[N:], dim=0)[:, fo:fo + co].to(torch.float64)       # [(N+1) L][co]
+        n_y = (N + 1) * L
+        n_fft = 1
+        while n_fft < L + taps:
+            n_fft *= 2
+        integer_io = fmt == "S24_4LE"
+        xs = x[:, probe].to(torch.float64)                                      # counts (S24) or reals
+        X = torch.fft.rfft(xs, n=n_fft, dim=0)
+        worst, worst_rel, checked = 0.0, 0.0, 0
+        for o in range(fo, fo + co):
+            want = torch.zeros(n_y, dtype=torch.float64, device=device)
+            for j, i in enumerate(probe):
+                if args.workload in DIAGONAL and i != o:
+                    continue
+                # (BFHIP_BENCH_VERIFY_SELFTEST=1, tests only: expect the WRONG filter behind the last probe
+                # input -- the check has to notice and the run has to fail)
+                wrong = 1 if (os.environ.get("BFHIP_BENCH_VERIFY_SELFTEST") == "1" and i == probe[-1]) else 0
+                h = synth_ir_dev(torch, 4321 + o * I + i + wrong, taps, 1 if args.workload in DIAGONAL else I, device).to(tdt)
+                want += torch.fft.irfft(X[:, j] * torch.fft.rfft(h.to(torch.float64), n=n_fft), n=n_fft)[:n_y]
+            err = (got[:, o - fo] - want).abs().max().item()
+            worst = max(worst, err)
+            worst_rel = max(worst_rel, err / max(want.abs().max().item(), 1e-300)) if want.abs().max().item() > 0 else worst_rel
+            checked += 1
+        # integer output: within one count of the exact value (rounding + the float32 transforms);
+        # float64 in and out: the working precision
+        ok = (worst <= 1.0) if integer_io else (worst_rel <= 1e-9)
+        return {"ok": bool(ok and st == 0), "status_bits": st, "outputs_checked": checked, "blocks": N + 1,
+                "probe_inputs": probe, "max_abs_err": worst, "max_err_rel_to_peak": worst_rel,
+                "unit": "LSB of S24" if integer_io else "output units",
+                "against": "float64 torch.fft convolution of the probe block with the loaded impulse responses"}
+
+    ver = None
+    if not args.no_verify and not args.host_io:
+        ver = verify()
+        if dist is not None:
+            allv = [None] * world
+            dist.all_gather_object(allv, ver)
+            ver = dict(allv[0], ok=all(v["ok"] for v in allv), max_abs_err=max(v["max_abs_err"] for v in allv),
+                       max_err_rel_to_peak=max(v["max_err_rel_to_peak"] for v in allv),
+                       outputs_checked=sum(v["outputs_checked"] for v in allv), ranks=world)
 
     def mac_roofline(tm_, alg_mac):
         mac_s = tm_["mac_ms"] * 1e-3
@@ -670,6 +742,7 @@ def main():
         if args.host_io:
             out["config"]["io"] = "host buffers through bfhip_engine_rt_submit/rt_wait, two blocks in flight (PCIe-inclusive)"
         out["source_hash"] = src_hash
+        out["verify"] = ver
         if world == 1:
             traffic, traffic_stale, traffic_src = None, None, None
             tp = os.path.join(ROOT, "profiles", "traffic_config%s.json" % args.workload)
@@ -708,6 +781,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if ver is not None and not ver["ok"]:
+        raise SystemExit("bench.py: the outputs of the timed configuration are WRONG: %s" % json.dumps(ver))
 
 
 if __name__ == "__main__":

@@ -161,6 +161,9 @@ def test_bench_two_rank_pipeline_on_one_gpu():
         assert p["mac_ms"] > 0 and p["roofline"]["achieved"] > 0
         assert p["roofline"]["algorithmic_bytes_per_launch"] > 0
     assert d["roofline"]["frac"] > 0 and "exposed_collective_ms" in d
+    # the line carries its own end-to-end check of the sharded outputs (mix-down included)
+    v = d["verify"]
+    assert v["ok"] and v["ranks"] == 2 and v["outputs_checked"] == 8 and v["max_abs_err"] <= 1.0
 
 
 def test_bench_refuses_two_ranks_on_one_device_under_the_rccl_headline():
@@ -199,3 +202,26 @@ def test_bench_step_loop_with_a_real_rccl_reduce_scatter_on_one_rank():
     assert d["backend"].startswith("rccl") and "RCCL reduce-scatter" in d["metric"]
     assert d["config"]["status_bits"] == 0 and d["value"] > 0
     assert d["exposed_collective_ms"] is not None and d["exposed_collective_ms"] >= 0
+    assert d["verify"]["ok"] and d["verify"]["max_abs_err"] <= 1.0          # outputs behind the RCCL call are right
+
+
+def test_bench_verification_notices_wrong_outputs():
+    """bench.py checks the outputs of the configuration it has just timed against a float64
+    convolution with the loaded impulse responses and fails the run when they differ.  With the
+    test hook that makes it EXPECT another filter the run must exit non-zero and say so (the line
+    is still printed, `verify.ok` false); without the hook the same run passes."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BFHIP_DIST_BACKEND"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "4", "--workload", "B",
+           "--no-cpu-baseline"]
+    good = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env)
+    assert good.returncode == 0, good.stderr[-2000:]
+    v = json.loads([ln for ln in good.stdout.splitlines() if ln.startswith("{")][0])["verify"]
+    assert v["ok"] and v["outputs_checked"] == 8 and v["probe_inputs"] == [0, 7] and 0 < v["max_abs_err"] <= 1.0
+    bad = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=dict(env, BFHIP_BENCH_VERIFY_SELFTEST="1"))
+    assert bad.returncode != 0 and "WRONG" in bad.stderr
+    v = json.loads([ln for ln in bad.stdout.splitlines() if ln.startswith("{")][0])["verify"]
+    assert not v["ok"] and v["max_abs_err"] > 10.0
