@@ -1,9 +1,18 @@
-set -e
-mkdir -p gpurun_out/r02c
-for w in B D E; do python bench.py --workload $w --no-cpu-baseline > gpurun_out/r02c/bench_config$w.json 2>/dev/null; echo "$w rc=$?"; done
-python bench.py --host-io --no-cpu-baseline > gpurun_out/r02c/bench_configC_hostio.json 2>/dev/null; echo "hostio rc=$?"
-for n in 2 4 8; do BFHIP_BENCH_REHEARSE_RANKS=$n python bench.py --no-cpu-baseline > gpurun_out/r02c/bench_configC_rank0of${n}_rehearsal.json 2>/dev/null; echo "rehearse $n rc=$?"; done
-for w in C2 C4 C8; do python bench.py --workload $w --no-cpu-baseline > gpurun_out/r02c/bench_config$w.json 2>/dev/null; echo "$w rc=$?"; done
-BFHIP_BENCH_REHEARSE_RANKS=8 BFHIP_BENCH_REHEARSE_RCCL=1 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r02c/bench_configC_rank0of8_rccl_one_rank.json; echo "rccl rc=$?"
-BFHIP_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 40 --warmup 10 --no-cpu-baseline > gpurun_out/r02c/bench_configC_2rank_gloo_rehearsal.json 2>/dev/null; echo "gloo2 rc=$?"
-python tools/nupc_latency.py > gpurun_out/r02c/nupc_latency.json 2> gpurun_out/r02c/nupc_latency.err; echo "nupc rc=$?"
+#!/bin/bash
+# Re-measure every bench line kept under profiles/ on the current sources (run ON THE GPU BOX):
+#   gpurun --timeout 1100 -- 'bash tools/refresh_profiles.sh r02'
+# then copy gpurun_out/<tag>/bench_*.json to profiles/<tag>_bench_*.json.  The kernel statistics and
+# PMC traffic of configs C and F come from tools/profile_round.sh.
+TAG=${1:-r02}
+OUT=gpurun_out/$TAG
+mkdir -p "$OUT"
+run() { name=$1; shift; "$@" 2> "$OUT/$name.err" | tail -1 > "$OUT/bench_$name.json"; echo "$name rc=${PIPESTATUS[0]}"; }
+run configC python bench.py
+run configF python bench.py --workload F
+for w in B D E C2 C4 C8; do run config$w python bench.py --workload $w --no-cpu-baseline; done
+run configC_hostio python bench.py --host-io --no-cpu-baseline
+for n in 2 4 8; do BFHIP_BENCH_REHEARSE_RANKS=$n run configC_rank0of${n}_rehearsal python bench.py --no-cpu-baseline; done
+BFHIP_BENCH_REHEARSE_RANKS=8 BFHIP_BENCH_REHEARSE_RCCL=1 run configC_rank0of8_rccl_one_rank python bench.py --no-cpu-baseline
+BFHIP_BENCH_REHEARSE_RANKS=8 BFHIP_BENCH_REHEARSE_RCCL=1 run configD_rank0of8_rccl_one_rank python bench.py --workload D --no-cpu-baseline
+BFHIP_DIST_BACKEND=gloo run configC_2rank_gloo_rehearsal python bench.py --gpus 2 --steps 40 --warmup 10 --no-cpu-baseline
+BFHIP_DIST_BACKEND=gloo run configD_2ranks_gloo_one_gpu python bench.py --gpus 2 --workload D --steps 40 --warmup 10 --no-cpu-baseline
