@@ -351,7 +351,7 @@ def self_launch(n, argv):
     if rc == 0 and not lines:
         sys.stderr.write("bench.py: rank 0 printed no result line\n")
         rc = 1
-    if rc == 0:
+    if lines:                         # also when a rank failed afterwards (verify.ok false): the line says why
         sys.stdout.write(lines[-1])
         sys.stdout.flush()
     return rc
