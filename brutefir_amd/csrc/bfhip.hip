@@ -252,6 +252,9 @@ struct bfhip_engine {
     std::vector<Filter> filters;
     bool finalized = false, finalize_failed = false, plan_dirty = true;
     unsigned int blockcounter = 0;
+    // ... which wraps by a multiple of every ring depth (N, and N + 1 when a spare slot exists)
+    // long before 2^32, so that `blockcounter mod depth` never jumps (BlockState, kernels.h)
+    unsigned int wrap_at = 0, wrap_by = 0;
     unsigned long long blocks_done = 0;      // since creation (procblocks analogue)
 
     hipStream_t stream = nullptr;      // main stream: per-filter kernels and the crossbar MAC
@@ -1625,7 +1628,8 @@ void advance(bfhip_engine *e) {
         if (e->timed_mask) { e->ev_mask[e->ev_used] = (unsigned char)e->timed_mask; e->ev_used++; }
         e->timed_now = false;
     }
-    e->blockcounter++;                                   // bfrun.c:2034 (unsigned wrap)
+    e->blockcounter++;                                   // bfrun.c:2034
+    if (e->wrap_by != 0u && e->blockcounter >= e->wrap_at) e->blockcounter -= e->wrap_by;
     e->blocks_done++;
     for (auto &f : e->filters) f.prevcoeff = f.coeff;    // bfrun.c:1838
     if (e->any_fading) e->plan_dirty = true;             // the fade lasts exactly one block
@@ -2426,6 +2430,21 @@ static int finalize_impl(bfhip_engine *e) {
         if (const char *env = getenv("BFHIP_PIPE2")) e->pipe2 = e->pipe2 && atoi(env) != 0;
     }
     e->R = e->pipelined ? e->N + 1 : e->N;
+    {
+        // the shared rings are R deep, the private ones N: the counter wraps by a multiple of both
+        const unsigned long long period = e->R == e->N ? (unsigned long long)e->N : (unsigned long long)e->N * e->R;
+        if (period <= (1ull << 30)) {
+            e->wrap_by = (unsigned int)((0x7fffffffull / period) * period);
+            e->wrap_at = e->wrap_by + 2u * (unsigned int)e->R;           // t - p - delay stays >= 0
+        }
+        if (const char *env = getenv("BFHIP_TEST_WRAP_PERIODS")) {       // tests: wrap after a few ring periods
+            e->wrap_by = (unsigned int)(std::max(1, atoi(env)) * period);
+            // (... and BFHIP_TEST_WRAP_SKEW: by a few blocks more, i.e. NOT a multiple of the depths --
+            // what a wrap at 2^32 is for such depths; the tests want to see that go wrong)
+            if (const char *skew = getenv("BFHIP_TEST_WRAP_SKEW")) e->wrap_by += (unsigned int)atoi(skew);
+            e->wrap_at = e->wrap_by + 2u * (unsigned int)e->R;
+        }
+    }
     // the MAC addresses a ring / a coefficient set with 32-bit byte offsets from its base
     if ((double)(e->N + 1) * (double)L * (double)e->csize() >= 4294967296.0)
         return fail(BFHIP_EINVAL, "%d partitions of %d taps: a coefficient set would exceed 4 GiB", e->N, e->L);
@@ -2992,6 +3011,7 @@ int bfhip_engine_rt_submit(bfhip_engine *e, const void *rawin) {
         bs.t = e->blockcounter;
         bs.age = (int)std::min<unsigned long long>(e->blocks_done + 1, (unsigned long long)e->N);
         bs.n_blocks = 0; bs.pad = 0;
+        bs.wrap_at = e->wrap_at; bs.wrap_by = e->wrap_by;
         HIPCHK(hipMemcpyAsync(e->d_bs, &bs, sizeof(bs), hipMemcpyHostToDevice, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
         rt.bs_synced = true;

@@ -83,7 +83,11 @@ struct StreamLayout {
 // kernel arguments are frozen at capture time): t = blockcounter (bfrun.c:2034), age =
 // min(blocks processed + 1, N) (the procblocks guard, bfrun.c:1745).  Kernels take an optional
 // pointer to it; null = use the by-value arguments.  rt_tail_kernel advances it.
-struct BlockState { unsigned int t; int age; int n_blocks; int pad; };
+// The counter does not run up to 2^32 like the reference's: slots are `t mod ring depth`, and a
+// depth that is not a power of two (N = 13, or the spare slot of the pipelined schedules, N + 1)
+// would jump at the wrap -- after 66 days of 64-frame blocks.  It wraps from wrap_at by wrap_by, a
+// multiple of every ring depth in the engine, instead (wrap_by = 0: plain unsigned wrap).
+struct BlockState { unsigned int t; int age; int n_blocks; unsigned int wrap_at, wrap_by; int pad; };
 
 // ------------------------------------------------------------------ raw sample access
 
@@ -1949,7 +1953,9 @@ rt_tail_kernel(RtCopy c, BlockState *__restrict__ bs, int N, const DevOverflow *
         if (threadIdx.x == 0) {
             host_status[0] = *status;
             *status = 0;
-            bs->t = bs->t + 1u;                              // bfrun.c:2034, unsigned wrap
+            unsigned int tn = bs->t + 1u;                    // bfrun.c:2034
+            if (bs->wrap_by != 0u && tn >= bs->wrap_at) tn -= bs->wrap_by;
+            bs->t = tn;
             bs->age = bs->age < N ? bs->age + 1 : N;
             bs->n_blocks = bs->n_blocks + 1;
         }

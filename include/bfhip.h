@@ -325,6 +325,9 @@ int bfhip_engine_set_stream(bfhip_engine *e, void *hip_stream);
 
 int bfhip_engine_get_overflow(bfhip_engine *e, int out_channel, bfhip_overflow *of);
 int bfhip_engine_reset_overflow(bfhip_engine *e);     /* bf_reset_peak(), bfrun.c */
+/* the engine's block counter (bfrun.c:2034).  It wraps by a multiple of the ring depths long
+   before 2^32 (so that `counter mod depth` never jumps, also for depths that are not powers of
+   two): do not use it to count blocks over long runs */
 unsigned int bfhip_engine_blockcounter(const bfhip_engine *e);
 /* how bfhip_engine_block_dev schedules the kernels of a block (decided at finalize): */
 #define BFHIP_MODE_SEQUENTIAL 0   /* K1, MAC, K3 of a block in order on one stream                 */
