@@ -83,7 +83,7 @@ struct Stage {
     static constexpr int K = 4;
     uint8_t *base = nullptr;
     size_t slot = 0;
-    int turn = 0;
+    unsigned int turn = 0;             // (unsigned: a stream of 64-frame blocks passes 2^31 in a month)
     hipEvent_t done[K] = {nullptr, nullptr, nullptr, nullptr};
     bool pending[K] = {false, false, false, false};
 
@@ -99,14 +99,14 @@ struct Stage {
     }
     // next slot, free again once the copy queued from it K blocks ago has run
     hipError_t take(uint8_t **p) {
-        const int i = turn++ % K;
+        const int i = (int)(turn++ % (unsigned int)K);
         if (pending[i]) { const hipError_t r = hipEventSynchronize(done[i]); if (r != hipSuccess) return r; pending[i] = false; }
         *p = base + (size_t)i * slot;
         return hipSuccess;
     }
     // the copies out of the slot handed out last have been queued on st
     hipError_t queued(hipStream_t st) {
-        const int i = (turn - 1) % K;
+        const int i = (int)((turn - 1u) % (unsigned int)K);
         const hipError_t r = hipEventRecord(done[i], st);
         pending[i] = r == hipSuccess;
         return r;

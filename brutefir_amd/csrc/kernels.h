@@ -87,7 +87,7 @@ struct StreamLayout {
 // depth that is not a power of two (N = 13, or the spare slot of the pipelined schedules, N + 1)
 // would jump at the wrap -- after 66 days of 64-frame blocks.  It wraps from wrap_at by wrap_by, a
 // multiple of every ring depth in the engine, instead (wrap_by = 0: plain unsigned wrap).
-struct BlockState { unsigned int t; int age; int n_blocks; unsigned int wrap_at, wrap_by; int pad; };
+struct BlockState { unsigned int t; int age; unsigned int n_blocks; unsigned int wrap_at, wrap_by; int pad; };
 
 // ------------------------------------------------------------------ raw sample access
 
@@ -1957,7 +1957,7 @@ rt_tail_kernel(RtCopy c, BlockState *__restrict__ bs, int N, const DevOverflow *
             if (bs->wrap_by != 0u && tn >= bs->wrap_at) tn -= bs->wrap_by;
             bs->t = tn;
             bs->age = bs->age < N ? bs->age + 1 : N;
-            bs->n_blocks = bs->n_blocks + 1;
+            bs->n_blocks = bs->n_blocks + 1u;
         }
     }
     __threadfence_system();

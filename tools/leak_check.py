@@ -93,7 +93,68 @@ def two(k):
     del x, y
 
 
+def long_run(n_blocks=3000, shared_inputs=True):
+    """ONE engine that lives long: a control change on every block (coefficient toggles with
+    cross-fades, scale and block-delay changes -- the first of each gives the filter a private ring
+    --, sample-delay changes on N:1 channels, a coefficient partition refreshed in place), first
+    through the block call, then in real-time mode, where every plan change re-captures the
+    graphs.  Device AND host memory must stay where they are after the first few hundred blocks."""
+    import resource
+    rng = np.random.default_rng(77)
+    L, N = 256, 4
+    e = bf.Engine(L, N, 4, 3, 3)
+    if shared_inputs:
+        e.map_channels(0, [0, 1, 1])                      # inputs 1 and 2 share a physical channel:
+        e.set_interleaved_phys(0, "S24_4LE", 2)           # per-block job tables, no graph replay
+        for v in (1, 2):
+            e.set_maxdelay(0, v, 600)
+    else:
+        e.set_interleaved(0, "S24_4LE")                   # replayable: plan changes re-capture the graphs
+    e.set_interleaved(1, "S24_4LE")
+    cs = [e.add_coeff((rng.standard_normal(L * N) / 200).astype(np.float32)) for _ in range(3)]
+    e.add_filter(in_ch=[0], out_ch=[0], coeff=cs[0], crossfade=True)
+    e.add_filter(in_ch=[1], out_ch=[1], coeff=cs[1])
+    e.add_filter(in_ch=[0, 2], out_ch=[2], coeff=cs[2])
+    e.add_filter(in_f=[1], out_ch=[0], coeff=-1)
+    e.finalize()
+    x = (rng.standard_normal((L, 2 if shared_inputs else 3)) * 1e5).astype(np.int32)
+    marks = []
+
+    def control(k):
+        if not shared_inputs and k % 3:
+            return                                        # leave blocks for the graphs to replay
+        e.set_coeff(0, cs[(k // 3) % 2])
+        if k % 3 == 0:
+            e.set_scale(1, 0, 0, 1.0 + (k % 5) * 0.1)
+        if k % 7 == 0:
+            e.set_delayblocks(1, k % N)
+        if shared_inputs and k % 5 == 0:
+            e.set_delay(0, 1 + k % 2, (37 * k) % 600)
+        if k % 11 == 0:
+            e.update_coeff_block(cs[2], k % N, (rng.standard_normal(L) / 200).astype(np.float32))
+
+    for k in range(n_blocks):
+        if k == n_blocks // 2:
+            e.rt_begin(0)
+        control(k)
+        st, _ = e.block(x) if k < n_blocks // 2 else e.rt_block(x)
+        assert st == 0, (k, st)
+        if k % 500 == 499:
+            marks.append((free_mib(), resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0))
+    stats = e.rt_stats()
+    e.rt_end()
+    e.close()
+    print("long run (%s): %d blocks, %d graph captures, %d replayed; (device free MiB, host max RSS MiB) every 500 blocks: %s"
+          % ("N:1 inputs" if shared_inputs else "replayable", n_blocks, stats["captures"], stats["graph"],
+             ["%.1f/%.0f" % m for m in marks]))
+    assert shared_inputs or stats["captures"] > 100
+    assert abs(marks[0][0] - marks[-1][0]) < 8, "device memory moves with the number of blocks"
+    assert marks[-1][1] - marks[1][1] < 64, "host memory grows with the number of blocks"
+
+
 def main():
+    long_run(shared_inputs=True)
+    long_run(shared_inputs=False)
     for k in range(20):
         one(k)
         two(k)
