@@ -1,0 +1,26 @@
+#!/bin/bash
+# Copy what tools/profile_round.sh and tools/refresh_profiles.sh left under gpurun_out/<tag>/ into
+# profiles/ under the round's prefix (run in the build container after the gpurun call):
+#   bash tools/install_profiles.sh r02f r02
+TAG=${1:?tag under gpurun_out/}; PFX=${2:-r02}
+cd "$(dirname "$0")/.."
+S=gpurun_out/$TAG
+for w in C F; do
+  [ -f $S/traffic_config$w.json ] && cp $S/traffic_config$w.json profiles/traffic_config$w.json
+  for f in config${w}_bench_kernel_stats.csv config${w}_fetch_summary.json config${w}_write_summary.json config${w}_bench_ktrace_summary.json; do
+    [ -f $S/$f ] && cp $S/$f profiles/${PFX}_$f
+  done
+done
+for f in $S/bench_*.json; do [ -s "$f" ] && cp "$f" profiles/${PFX}_$(basename $f); done
+python3 - <<'PY'
+import glob, json, os, sys
+sys.path.insert(0, os.getcwd())
+import bench
+h = bench.source_hash()
+for f in sorted(glob.glob("profiles/traffic_config*.json")):
+    print(f, json.load(open(f))["source_hash"], "(sources now %s)" % h)
+for f in sorted(glob.glob("profiles/*_bench_config[CF].json")):
+    j = json.loads(open(f).read().strip().splitlines()[-1])
+    print(f, "ms %.4f" % j["ms_per_step"], "frac %.3f" % j["roofline"]["frac"], "traffic_stale", j["roofline"]["traffic_stale"],
+          "verify", j.get("verify", {}).get("ok"))
+PY
