@@ -2,7 +2,7 @@
 # Copy what tools/profile_round.sh and tools/refresh_profiles.sh left under gpurun_out/<tag>/ into
 # profiles/ under the round's prefix (run in the build container after the gpurun call):
 #   bash tools/install_profiles.sh r02f r02
-TAG=${1:?tag under gpurun_out/}; PFX=${2:-r02}
+TAG=${1:?tag under gpurun_out/}; PFX=${2:-r02}    # the tag directory must be fresh: everything in it is copied
 cd "$(dirname "$0")/.."
 S=gpurun_out/$TAG
 for w in C F; do
