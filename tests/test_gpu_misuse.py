@@ -161,3 +161,41 @@ def test_a_configuration_that_does_not_fit_the_device_is_an_error_not_a_crash(hi
     blk = cases.raw_blocks(5, 1, L, I, "S24_4LE")[0]
     assert np.abs(np.frombuffer(ge.block(blk)[1].tobytes(), np.int32).astype(np.int64)
                   - oe.block(blk)[1].view(np.int32)).max() <= 1
+
+
+@pytest.mark.parametrize("rs", [4, 8])
+def test_degenerate_networks(hip, rs):
+    """no filter at all; outputs nothing feeds; a filter that feeds nothing; the smallest engine
+    there is (L = 4, one partition, one channel) -- against the oracle"""
+    def both(spec_fn, L_, N_, I_, O_, n_blocks=4):
+        outs = []
+        for cls in (hip.Engine, bo.Engine):
+            e = cls(L_, N_, rs, I_, O_)
+            e.set_interleaved(0, "S16_LE")
+            e.set_interleaved(1, "S24_4LE")
+            spec_fn(e)
+            if hasattr(e, "finalize"):
+                e.finalize()
+            res = []
+            for blk in cases.raw_blocks(21, n_blocks, L_, I_, "S16_LE", amplitude=0.3):
+                st, raw = e.block(blk)
+                assert st == 0
+                res.append(np.frombuffer(raw.tobytes(), np.int32).copy())
+            outs.append(np.concatenate(res))
+        assert np.abs(outs[0].astype(np.int64) - outs[1]).max() <= 1
+        return outs[0]
+
+    y = both(lambda e: None, 64, 2, 2, 3)                                   # no filter at all
+    assert not y.any()
+
+    def two_of_three(e):
+        c = e.add_coeff(cases.make_ir(np.random.default_rng(1), 128, 2).astype(np.float32 if rs == 4 else np.float64))
+        e.add_filter(in_ch=[0], out_ch=[1], coeff=c)                        # outputs 0 and 2 stay silent
+        e.add_filter(in_ch=[1], out_ch=[], coeff=c)                         # feeds nothing
+    y = both(two_of_three, 64, 2, 2, 3).reshape(-1, 3)
+    assert not y[:, 0].any() and not y[:, 2].any() and y[:, 1].any()
+
+    def tiny(e):
+        e.add_filter(in_ch=[0], out_ch=[0], coeff=e.add_coeff(np.array([0.5, 0.25, -0.125, 0.0625], np.float32 if rs == 4 else np.float64)))
+    y = both(tiny, 4, 1, 1, 1, n_blocks=6)
+    assert y.any()
