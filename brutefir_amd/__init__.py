@@ -124,6 +124,7 @@ def lib():
     L.bfhip_engine_blockcounter.argtypes = [vp]
     L.bfhip_engine_ring_depth.argtypes = [vp]
     L.bfhip_engine_block_mode.argtypes = [vp]
+    L.bfhip_selftest_fail_alloc.argtypes = [ci]
     L.bfhip_engine_output_lag.argtypes = [vp]
     L.bfhip_engine_flush.argtypes = [vp]
     L.bfhip_engine_uses_wave_fft.argtypes = [vp]

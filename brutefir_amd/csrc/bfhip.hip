@@ -34,6 +34,20 @@
 
 using namespace bfhip;
 
+// Every device / pinned allocation of the engine goes through these two, so that the tests can make
+// the n-th one fail (bfhip_selftest_fail_alloc) and walk every out-of-memory path there is.
+static int g_fail_alloc = 0;           // countdown: the allocation that takes it to zero fails
+static inline bool alloc_injected() { return g_fail_alloc > 0 && --g_fail_alloc == 0; }
+static hipError_t dev_alloc(void **p, size_t bytes) {
+    if (alloc_injected()) { *p = nullptr; return hipErrorOutOfMemory; }
+    return hipMalloc(p, bytes);
+}
+template <typename P> static hipError_t dev_alloc(P **p, size_t bytes) { return dev_alloc((void **)p, bytes); }
+static hipError_t pin_alloc(void **p, size_t bytes, unsigned int flags) {
+    if (alloc_injected()) { *p = nullptr; return hipErrorOutOfMemory; }
+    return hipHostMalloc(p, bytes, flags);
+}
+
 namespace {
 
 thread_local std::string g_err;
@@ -89,7 +103,7 @@ struct Stage {
 
     hipError_t init(size_t slot_bytes) {
         slot = (slot_bytes + 63) & ~(size_t)63;
-        hipError_t r = hipHostMalloc((void **)&base, slot * K, hipHostMallocDefault);
+        hipError_t r = pin_alloc((void **)&base, slot * K, hipHostMallocDefault);
         for (int i = 0; i < K && r == hipSuccess; i++) r = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
         return r;
     }
@@ -147,7 +161,7 @@ struct DelayLine {
             arena = (uint8_t *)calloc(total, 1);
             if (!arena) return BFHIP_ENOMEM;
         } else {
-            if (hipMalloc((void **)&arena, total) != hipSuccess) return BFHIP_ENOMEM;
+            if (dev_alloc((void **)&arena, total) != hipSuccess) return BFHIP_ENOMEM;
             if (hipMemset(arena, 0, total) != hipSuccess) return BFHIP_EHIP;
         }
         uint8_t *p = arena;
@@ -431,7 +445,7 @@ int sync_all(bfhip_engine *e) {
 void *coeff_alloc(bfhip_engine *e, size_t bytes) {
     if (!e->coeff_arena) {
         void *p = nullptr;
-        return hipMalloc(&p, bytes) == hipSuccess ? p : nullptr;
+        return dev_alloc(&p, bytes) == hipSuccess ? p : nullptr;
     }
     size_t need = (bytes + 65535) & ~(size_t)65535;                // sets start on 64 KiB
     size_t skew = 0;
@@ -454,7 +468,7 @@ void *coeff_alloc(bfhip_engine *e, size_t bytes) {
     if (const char *env = getenv("BFHIP_COEFF_SLAB_MB")) cap = (size_t)std::max(1, atoi(env)) << 20;
     cap = std::max(cap, need);
     bfhip_engine::Slab sl;
-    while (hipMalloc(&sl.base, cap) != hipSuccess) {
+    while (dev_alloc(&sl.base, cap) != hipSuccess) {
         (void)hipGetLastError();
         if (cap <= need) return nullptr;
         cap = std::max(need, cap / 2);
@@ -743,7 +757,7 @@ int big_reserve(bfhip_engine *e, size_t n_tr) {
     for (int i = 0; i < 3; i++) {
         if (e->d_big[i]) (void)hipFree(e->d_big[i]);
         e->d_big[i] = nullptr;
-        HIPCHK(hipMalloc(&e->d_big[i], n_tr * (size_t)e->L * e->csize()));
+        HIPCHK(dev_alloc(&e->d_big[i], n_tr * (size_t)e->L * e->csize()));
     }
     e->big_cap = n_tr;
     return BFHIP_OK;
@@ -902,7 +916,7 @@ int build_stream_layout(bfhip_engine *e, const std::vector<MacEntry<T>> &flat, c
         if (total > e->stream_cap) {
             if (e->d_stream) (void)hipFree(e->d_stream);
             e->d_stream = nullptr; e->stream_cap = 0;
-            if (hipMalloc(&e->d_stream, total) != hipSuccess) {
+            if (dev_alloc(&e->d_stream, total) != hipSuccess) {
                 (void)hipGetLastError();
                 return BFHIP_OK;                 // no room for the second copy: the set-major path still works
             }
@@ -934,7 +948,7 @@ int build_stream_layout(bfhip_engine *e, const std::vector<MacEntry<T>> &flat, c
         if (wb + cb > e->where_cap) {
             if (e->d_where) (void)hipFree(e->d_where);
             e->d_where = nullptr;
-            HIPCHK(hipMalloc((void **)&e->d_where, wb + flat.size() * sizeof(int)));
+            HIPCHK(dev_alloc((void **)&e->d_where, wb + flat.size() * sizeof(int)));
             e->where_cap = wb + flat.size() * sizeof(int);
         }
         e->d_which = (int *)((unsigned char *)e->d_where + wb);
@@ -1234,18 +1248,18 @@ int build_plan_t(bfhip_engine *e) {
     const size_t eb = std::max<size_t>(flat.size(), 1) * sizeof(MacEntry<T>);
     if (eb > e->entries_cap) {
         if (e->d_entries) (void)hipFree(e->d_entries);
-        HIPCHK(hipMalloc(&e->d_entries, eb));
+        HIPCHK(dev_alloc(&e->d_entries, eb));
         e->entries_cap = eb;
     }
     const size_t cb = chunks.size() * sizeof(ChunkRange);
     if (cb > e->chunks_cap) {
         if (e->d_chunks) (void)hipFree(e->d_chunks);
-        HIPCHK(hipMalloc((void **)&e->d_chunks, cb));
+        HIPCHK(dev_alloc((void **)&e->d_chunks, cb));
         e->chunks_cap = cb;
     }
     if (blob.size() > e->jobs_cap) {
         if (e->d_jobs) (void)hipFree(e->d_jobs);
-        HIPCHK(hipMalloc(&e->d_jobs, blob.size()));
+        HIPCHK(dev_alloc(&e->d_jobs, blob.size()));
         e->jobs_cap = blob.size();
     }
     { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
@@ -1262,9 +1276,9 @@ int build_plan_t(bfhip_engine *e) {
         if (e->d_Zp2) (void)hipFree(e->d_Zp2);
         if (e->d_Zp3) (void)hipFree(e->d_Zp3);
         e->d_Zp2 = nullptr; e->d_Zp3 = nullptr;
-        HIPCHK(hipMalloc(&e->d_Zp, zb));
-        if (e->pipelined || e->defer_out) HIPCHK(hipMalloc(&e->d_Zp2, zb));
-        if (e->pipe2) HIPCHK(hipMalloc(&e->d_Zp3, zb));
+        HIPCHK(dev_alloc(&e->d_Zp, zb));
+        if (e->pipelined || e->defer_out) HIPCHK(dev_alloc(&e->d_Zp2, zb));
+        if (e->pipe2) HIPCHK(dev_alloc(&e->d_Zp3, zb));
         e->zp_bytes = zb;
     }
 
@@ -1829,17 +1843,17 @@ int subdelay_setup(bfhip_engine *e) {
             memcpy(bank.data() + (size_t)(99 + sd) * e->sd_flen * 8, f.data(), f.size() * 8);
         }
     }
-    HIPCHK(hipMalloc(&e->d_sd_bank, bank.size()));
+    HIPCHK(dev_alloc(&e->d_sd_bank, bank.size()));
     HIPCHK(hipMemcpy(e->d_sd_bank, bank.data(), bank.size(), hipMemcpyHostToDevice));
     for (int io = 0; io < 2; io++) {
         if (n_slots[io] == 0) continue;
-        HIPCHK(hipMalloc(&e->d_sd_rest[io], (size_t)n_slots[io] * e->sd_bs * e->rs));
+        HIPCHK(dev_alloc(&e->d_sd_rest[io], (size_t)n_slots[io] * e->sd_bs * e->rs));
         HIPCHK(hipMemset(e->d_sd_rest[io], 0, (size_t)n_slots[io] * e->sd_bs * e->rs));
-        HIPCHK(hipMalloc(&e->d_sdjobs[io], (size_t)n_slots[io] * 128));
+        HIPCHK(dev_alloc(&e->d_sdjobs[io], (size_t)n_slots[io] * 128));
         HIPCHK(e->st_sd[io].init((size_t)n_slots[io] * 128));
     }
     if (n_slots[0] > 0) {
-        HIPCHK(hipMalloc(&e->d_sdin, (size_t)n_slots[0] * e->L * e->rs));
+        HIPCHK(dev_alloc(&e->d_sdin, (size_t)n_slots[0] * e->L * e->rs));
         HIPCHK(hipMemset(e->d_sdin, 0, (size_t)n_slots[0] * e->L * e->rs));
     }
     return BFHIP_OK;
@@ -1908,12 +1922,12 @@ bfhip_engine *bfhip_engine_create(int device, int length, int n_blocks, int real
     while ((1 << log2l) < length) log2l++;
     const std::vector<unsigned char> tw = make_twiddle_table(log2l, realsize,
         realsize == 4 ? fft_threads<float>(log2l) : fft_threads<double>(log2l));
-    ok = ok && hipMalloc(&e->d_tw, tw.size()) == hipSuccess;
+    ok = ok && dev_alloc(&e->d_tw, tw.size()) == hipSuccess;
     ok = ok && hipMemcpy(e->d_tw, tw.data(), tw.size(), hipMemcpyHostToDevice) == hipSuccess;
     if (e->big) {
         const std::vector<unsigned char> tw13 = make_twiddle_table(BIG_LOG2M, realsize,
             realsize == 4 ? fft_threads<float>(BIG_LOG2M) : fft_threads<double>(BIG_LOG2M));
-        ok = ok && hipMalloc(&e->d_tw13, tw13.size()) == hipSuccess;
+        ok = ok && dev_alloc(&e->d_tw13, tw13.size()) == hipSuccess;
         ok = ok && hipMemcpy(e->d_tw13, tw13.data(), tw13.size(), hipMemcpyHostToDevice) == hipSuccess;
     }
     // default from L = 4096 up: below that a workgroup of L/16 threads is one or two waves and the
@@ -1925,13 +1939,14 @@ bfhip_engine *bfhip_engine_create(int device, int length, int n_blocks, int real
     if (const char *env = getenv("BFHIP_FFT_WAVE")) e->wave = wave_fft_ok(lg, realsize) && atoi(env) != 0;
     if (e->wave) {
         const std::vector<unsigned char> tww = make_wave_twiddle_table(lg, realsize);
-        ok = ok && hipMalloc(&e->d_tww, tww.size()) == hipSuccess;
+        ok = ok && dev_alloc(&e->d_tww, tww.size()) == hipSuccess;
         ok = ok && hipMemcpy(e->d_tww, tww.data(), tww.size(), hipMemcpyHostToDevice) == hipSuccess;
     }
-    ok = ok && hipMalloc((void **)&e->d_bad, sizeof(int)) == hipSuccess;
+    ok = ok && dev_alloc((void **)&e->d_bad, sizeof(int)) == hipSuccess;
     ok = ok && hipMemset(e->d_bad, 0, sizeof(int)) == hipSuccess;
     if (!ok) {
-        fail(BFHIP_EHIP, "device set-up failed: %s", hipGetErrorString(hipGetLastError()));
+        const hipError_t le = hipGetLastError();
+        fail(BFHIP_EHIP, "device set-up failed: %s", le == hipSuccess ? "out of device memory" : hipGetErrorString(le));
         bfhip_engine_destroy(e);
         return nullptr;
     }
@@ -2097,9 +2112,9 @@ int bfhip_engine_enable_dither(bfhip_engine *e, const int out_channels[], int n,
 static int dither_upload(bfhip_engine *e) {
     const int n = (int)e->dither_channels.size();
     if (n == 0) return BFHIP_OK;
-    HIPCHK(hipMalloc((void **)&e->d_dither_ch, n * sizeof(int)));
+    HIPCHK(dev_alloc((void **)&e->d_dither_ch, n * sizeof(int)));
     HIPCHK(hipMemcpy(e->d_dither_ch, e->dither_channels.data(), n * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc((void **)&e->d_dither_table, e->dither_table.size()));
+    HIPCHK(dev_alloc((void **)&e->d_dither_table, e->dither_table.size()));
     HIPCHK(hipMemcpy(e->d_dither_table, e->dither_table.data(), e->dither_table.size(), hipMemcpyHostToDevice));
     // randmap[d] = 0.5 + (d + 1)/255 for d in -255..253, [-256] = -0.5, [254] = 1.5
     // (dither.c:115-131).  The reference indexes it with int8 - int8, which can be +255: one
@@ -2114,13 +2129,13 @@ static int dither_upload(bfhip_engine *e) {
             ((double *)map.data())[d + 256] = v;
         }
     }
-    HIPCHK(hipMalloc(&e->d_randmap, map.size()));
+    HIPCHK(dev_alloc(&e->d_randmap, map.size()));
     HIPCHK(hipMemcpy(e->d_randmap, map.data(), map.size(), hipMemcpyHostToDevice));
     // per-slot state: ptr = n*spacing + 1, error feedback zero (dither.c:133-137)
     const size_t ssz = e->rs == 4 ? sizeof(DitherState<float>) : sizeof(DitherState<double>);
     std::vector<unsigned char> stv(ssz * n, 0);
     for (int i = 0; i < n; i++) *(int *)(stv.data() + ssz * i) = e->dither_rank[i] * e->dither_spacing + 1;
-    HIPCHK(hipMalloc(&e->d_dither_state, stv.size()));
+    HIPCHK(dev_alloc(&e->d_dither_state, stv.size()));
     HIPCHK(hipMemcpy(e->d_dither_state, stv.data(), stv.size(), hipMemcpyHostToDevice));
     return BFHIP_OK;             // d_skip_quant / d_timeout: allocated with the channel set-up in finalize
 }
@@ -2139,7 +2154,7 @@ static int add_coeff_common(bfhip_engine *e, const void *taps, bool on_device, i
         const size_t bytes = (size_t)n_taps * e->rs;
         if (bytes > e->taps_cap) {
             if (e->d_taps) { { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; } (void)hipFree(e->d_taps); e->d_taps = nullptr; }
-            HIPCHK(hipMalloc(&e->d_taps, bytes));
+            HIPCHK(dev_alloc(&e->d_taps, bytes));
             e->taps_cap = bytes;
         }
         { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
@@ -2180,7 +2195,7 @@ int bfhip_engine_reserve_coeffs(bfhip_engine *e, double total_bytes) {
     const size_t want = ((size_t)(total_bytes * 1.05) + ((size_t)1 << 20) + 65535) & ~(size_t)65535;
     if (!e->slabs.empty() && e->slabs.back().cap - e->slabs.back().used >= want) return BFHIP_OK;
     bfhip_engine::Slab sl;
-    if (hipMalloc(&sl.base, want) != hipSuccess) {
+    if (dev_alloc(&sl.base, want) != hipSuccess) {
         (void)hipGetLastError();
         return fail(BFHIP_ENOMEM, "out of device memory reserving %.0f bytes of coefficient memory", total_bytes);
     }
@@ -2207,7 +2222,7 @@ static int upload_processed_block(bfhip_engine *e, Coeff &c, int block, const vo
     const size_t bytes = n * e->rs;
     if (bytes > e->taps_cap) {
         if (e->d_taps) { { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; } (void)hipFree(e->d_taps); e->d_taps = nullptr; }
-        HIPCHK(hipMalloc(&e->d_taps, bytes));
+        HIPCHK(dev_alloc(&e->d_taps, bytes));
         e->taps_cap = bytes;
     }
     { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }      // d_taps is reused; nothing may still read H
@@ -2279,7 +2294,7 @@ int bfhip_engine_add_coeff_processed(bfhip_engine *e, const void *cbufs, int n_b
     const size_t bytes = n * e->rs;
     if (bytes > e->taps_cap) {
         if (e->d_taps) { { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; } (void)hipFree(e->d_taps); e->d_taps = nullptr; }
-        HIPCHK(hipMalloc(&e->d_taps, bytes));
+        HIPCHK(dev_alloc(&e->d_taps, bytes));
         e->taps_cap = bytes;
     }
     { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
@@ -2306,7 +2321,7 @@ int bfhip_engine_read_coeff_processed(bfhip_engine *e, int coeff, void *cbufs) {
     const size_t bytes = (size_t)nb * 2 * e->L * e->rs;
     if (bytes > e->taps_cap) {
         if (e->d_taps) { { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; } (void)hipFree(e->d_taps); e->d_taps = nullptr; }
-        HIPCHK(hipMalloc(&e->d_taps, bytes));
+        HIPCHK(dev_alloc(&e->d_taps, bytes));
         e->taps_cap = bytes;
     }
     const dim3 grid((e->L + 255) / 256, nb);
@@ -2328,7 +2343,7 @@ int bfhip_engine_update_coeff_block(bfhip_engine *e, int coeff, int block, const
     const size_t bytes = (size_t)e->L * e->rs;
     if (bytes > e->taps_cap) {
         if (e->d_taps) { { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; } (void)hipFree(e->d_taps); e->d_taps = nullptr; }
-        HIPCHK(hipMalloc(&e->d_taps, bytes));
+        HIPCHK(dev_alloc(&e->d_taps, bytes));
         e->taps_cap = bytes;
     }
     { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
@@ -2449,28 +2464,28 @@ static int finalize_impl(bfhip_engine *e) {
     if ((double)(e->N + 1) * (double)L * (double)e->csize() >= 4294967296.0)
         return fail(BFHIP_EINVAL, "%d partitions of %d taps: a coefficient set would exceed 4 GiB", e->N, e->L);
     const size_t ring_b = (size_t)e->n_ch[0] * e->R * L * e->csize();
-    if (hipMalloc(&e->d_prev, prev_b) != hipSuccess || hipMalloc(&e->d_ring, ring_b) != hipSuccess)
+    if (dev_alloc(&e->d_prev, prev_b) != hipSuccess || dev_alloc(&e->d_ring, ring_b) != hipSuccess)
         return fail(BFHIP_ENOMEM, "out of device memory for the spectrum rings");
     HIPCHK(hipMemset(e->d_prev, 0, prev_b));       // bfrun.c:1388: everything starts zeroed
     HIPCHK(hipMemset(e->d_ring, 0, ring_b));
     if (e->powersave > 0.0) {
         if (e->big) {
-            HIPCHK(hipMalloc((void **)&e->d_ps_acc, 2 * e->n_ch[0] * sizeof(unsigned long long)));
+            HIPCHK(dev_alloc((void **)&e->d_ps_acc, 2 * e->n_ch[0] * sizeof(unsigned long long)));
             HIPCHK(hipMemset(e->d_ps_acc, 0, 2 * e->n_ch[0] * sizeof(unsigned long long)));
         }
         {
             std::vector<int> ones((size_t)e->n_ch[0] * e->R, 1);     // the zeroed rings are silence
             std::vector<double> sc(e->n_ch[0]);
             for (int c = 0; c < e->n_ch[0]; c++) sc[c] = e->fmt[0][e->v2p[0][c]].scale;
-            HIPCHK(hipMalloc((void **)&e->d_ps_flags, ones.size() * sizeof(int)));
+            HIPCHK(dev_alloc((void **)&e->d_ps_flags, ones.size() * sizeof(int)));
             HIPCHK(hipMemcpy(e->d_ps_flags, ones.data(), ones.size() * sizeof(int), hipMemcpyHostToDevice));
-            HIPCHK(hipMalloc((void **)&e->d_ps_live, e->n_ch[0] * sizeof(int)));
+            HIPCHK(dev_alloc((void **)&e->d_ps_live, e->n_ch[0] * sizeof(int)));
             HIPCHK(hipMemset(e->d_ps_live, 0, e->n_ch[0] * sizeof(int)));
-            HIPCHK(hipMalloc((void **)&e->d_ps_scale, sc.size() * sizeof(double)));
+            HIPCHK(dev_alloc((void **)&e->d_ps_scale, sc.size() * sizeof(double)));
             HIPCHK(hipMemcpy(e->d_ps_scale, sc.data(), sc.size() * sizeof(double), hipMemcpyHostToDevice));
         }
     }
-    for (int io = 0; io < 2; io++) HIPCHK(hipMalloc((void **)&e->d_fmt[io], e->n_ch[io] * sizeof(DevFormat)));
+    for (int io = 0; io < 2; io++) HIPCHK(dev_alloc((void **)&e->d_fmt[io], e->n_ch[io] * sizeof(DevFormat)));
     { int rs_ = subdelay_setup(e); if (rs_ != BFHIP_OK) return rs_; }
     // channels that share a physical channel: private copies, delay lines, job tables
     {
@@ -2530,11 +2545,11 @@ static int finalize_impl(bfhip_engine *e) {
                 n_ops_max += e->vline[1][v].n_full_cap + 10;
             }
             if (!e->vin_list.empty()) {
-                HIPCHK(hipMalloc((void **)&e->d_incopy, e->vin_list.size() * (size_t)e->L * 8));
+                HIPCHK(dev_alloc((void **)&e->d_incopy, e->vin_list.size() * (size_t)e->L * 8));
                 HIPCHK(hipMemset(e->d_incopy, 0, e->vin_list.size() * (size_t)e->L * 8));
             }
             e->vjobs_slot = (n_ops_max + 8) * sizeof(ByteOp) + (e->n_ch[0] + e->n_ch[1] + 8) * 64;
-            HIPCHK(hipMalloc(&e->d_vjobs, 2 * e->vjobs_slot));
+            HIPCHK(dev_alloc(&e->d_vjobs, 2 * e->vjobs_slot));
             HIPCHK(e->st_vin.init(e->vjobs_slot));
             HIPCHK(e->st_vout.init(e->vjobs_slot));
             e->vline[0].resize(e->n_ch[0]); e->vline[1].resize(e->n_ch[1]);
@@ -2545,21 +2560,21 @@ static int finalize_impl(bfhip_engine *e) {
             std::vector<unsigned char> skip(e->n_ch[1], 0);
             for (auto &g : e->vout_groups) for (int v : g) skip[v] = 1;
             for (int c : e->dither_channels) skip[c] = 1;
-            HIPCHK(hipMalloc((void **)&e->d_skip_quant, skip.size()));
+            HIPCHK(dev_alloc((void **)&e->d_skip_quant, skip.size()));
             HIPCHK(hipMemcpy(e->d_skip_quant, skip.data(), skip.size(), hipMemcpyHostToDevice));
-            HIPCHK(hipMalloc(&e->d_timeout, (size_t)e->n_ch[1] * e->L * e->rs));
+            HIPCHK(dev_alloc(&e->d_timeout, (size_t)e->n_ch[1] * e->L * e->rs));
             HIPCHK(hipMemset(e->d_timeout, 0, (size_t)e->n_ch[1] * e->L * e->rs));
         }
     }
     int r = upload_formats(e);
     if (r != BFHIP_OK) return r;
-    HIPCHK(hipMalloc((void **)&e->d_over, e->n_ch[1] * sizeof(DevOverflow)));
-    HIPCHK(hipMalloc((void **)&e->d_status, sizeof(int)));
+    HIPCHK(dev_alloc((void **)&e->d_over, e->n_ch[1] * sizeof(DevOverflow)));
+    HIPCHK(dev_alloc((void **)&e->d_status, sizeof(int)));
     HIPCHK(hipMemset(e->d_status, 0, sizeof(int)));
     e->raw_bytes[0] = raw_extent(e->fmt[0], e->n_phys[0], e->L);
     e->raw_bytes[1] = raw_extent(e->fmt[1], e->n_phys[1], e->L);
-    HIPCHK(hipMalloc((void **)&e->d_rawin, e->raw_bytes[0] + 16));       // +16: staged in 16-byte words
-    HIPCHK(hipMalloc((void **)&e->d_rawout, e->raw_bytes[1] + 16));
+    HIPCHK(dev_alloc((void **)&e->d_rawin, e->raw_bytes[0] + 16));       // +16: staged in 16-byte words
+    HIPCHK(dev_alloc((void **)&e->d_rawout, e->raw_bytes[1] + 16));
     HIPCHK(hipMemset(e->d_rawout, 0, e->raw_bytes[1]));
     // classify filters: who owns a private ring, who must materialise its output
     {
@@ -2582,7 +2597,7 @@ static int finalize_impl(bfhip_engine *e) {
         e->n_levels = maxlevel + 1;
         auto zalloc = [&](void **p, size_t bytes) -> int {
             if (bytes == 0) return BFHIP_OK;
-            if (hipMalloc(p, bytes) != hipSuccess) return fail(BFHIP_ENOMEM, "out of device memory (%zu bytes)", bytes);
+            if (dev_alloc(p, bytes) != hipSuccess) return fail(BFHIP_ENOMEM, "out of device memory (%zu bytes)", bytes);
             HIPCHK(hipMemset(*p, 0, bytes));
             return BFHIP_OK;
         };
@@ -2624,7 +2639,7 @@ static int promote_filter(bfhip_engine *e, int fi) {
     HIPCHK(hipSetDevice(e->device));
     const size_t bytes = (size_t)e->N * e->L * e->csize();
     void *ring = nullptr;
-    if (hipMalloc(&ring, bytes) != hipSuccess) return fail(BFHIP_ENOMEM, "out of device memory for a private ring");
+    if (dev_alloc(&ring, bytes) != hipSuccess) return fail(BFHIP_ENOMEM, "out of device memory for a private ring");
     HIPCHK(hipMemsetAsync(ring, 0, bytes, e->stream));
     const int ch = f.in_ch[0];
     const int delay = clamp_delay(e, f.delayblocks);
@@ -2954,10 +2969,10 @@ int bfhip_engine_rt_begin(bfhip_engine *e, int flags) {
     auto &rt = e->rt;
     rt.flags = flags;
     for (int p = 0; p < 2; p++) {
-        HIPCHK(hipHostMalloc(&rt.h_in[p], e->raw_bytes[0] + 16, hipHostMallocDefault));
-        HIPCHK(hipHostMalloc(&rt.h_out[p], e->raw_bytes[1] + 16, hipHostMallocDefault));
-        HIPCHK(hipHostMalloc((void **)&rt.h_over[p], e->n_ch[1] * sizeof(DevOverflow), hipHostMallocDefault));
-        HIPCHK(hipHostMalloc((void **)&rt.h_status[p], 2 * sizeof(int), hipHostMallocDefault));
+        HIPCHK(pin_alloc(&rt.h_in[p], e->raw_bytes[0] + 16, hipHostMallocDefault));
+        HIPCHK(pin_alloc(&rt.h_out[p], e->raw_bytes[1] + 16, hipHostMallocDefault));
+        HIPCHK(pin_alloc((void **)&rt.h_over[p], e->n_ch[1] * sizeof(DevOverflow), hipHostMallocDefault));
+        HIPCHK(pin_alloc((void **)&rt.h_status[p], 2 * sizeof(int), hipHostMallocDefault));
         memset(rt.h_in[p], 0, e->raw_bytes[0]);
         memset(rt.h_out[p], 0, e->raw_bytes[1]);
         memset(rt.h_over[p], 0, e->n_ch[1] * sizeof(DevOverflow));
@@ -2966,8 +2981,8 @@ int bfhip_engine_rt_begin(bfhip_engine *e, int flags) {
         if (flags & BFHIP_RT_OVERLAP) {
             HIPCHK(hipEventCreateWithFlags(&rt.ev_h2d[p], hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&rt.ev_cmp[p], hipEventDisableTiming));
-            HIPCHK(hipMalloc((void **)&rt.d_in[p], e->raw_bytes[0] + 16));
-            HIPCHK(hipMalloc((void **)&rt.d_out[p], e->raw_bytes[1] + 16));
+            HIPCHK(dev_alloc((void **)&rt.d_in[p], e->raw_bytes[0] + 16));
+            HIPCHK(dev_alloc((void **)&rt.d_out[p], e->raw_bytes[1] + 16));
             HIPCHK(hipMemset(rt.d_out[p], 0, e->raw_bytes[1] + 16));
         }
     }
@@ -2975,8 +2990,8 @@ int bfhip_engine_rt_begin(bfhip_engine *e, int flags) {
         HIPCHK(hipStreamCreateWithFlags(&rt.s_h2d, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&rt.s_d2h, hipStreamNonBlocking));
     }
-    HIPCHK(hipMalloc((void **)&e->d_bs, sizeof(BlockState)));
-    HIPCHK(hipMalloc((void **)&e->d_rt_arrive, sizeof(unsigned int)));
+    HIPCHK(dev_alloc((void **)&e->d_bs, sizeof(BlockState)));
+    HIPCHK(dev_alloc((void **)&e->d_rt_arrive, sizeof(unsigned int)));
     HIPCHK(hipMemset(e->d_rt_arrive, 0, sizeof(unsigned int)));
     rt.on = true;
     rt.bs_synced = false;
@@ -3082,6 +3097,12 @@ int bfhip_engine_rt_stats(const bfhip_engine *e, unsigned long long *graph_block
 }
 
 // ---- self test of the wave FFT's host half: its per-thread twiddle table, no device involved ----
+int bfhip_selftest_fail_alloc(int nth) {
+    const int left = g_fail_alloc;             // > 0: the allocation armed before was never reached
+    g_fail_alloc = nth > 0 ? nth : 0;
+    return left;
+}
+
 int bfhip_selftest_wave_twiddles(int log2l, int realsize, void *out, int out_bytes) {
     if (!wave_fft_ok(log2l, realsize)) return fail(BFHIP_EINVAL, "selftest_wave_twiddles: length / precision not covered");
     const std::vector<unsigned char> t = make_wave_twiddle_table(log2l, realsize);

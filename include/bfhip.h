@@ -374,6 +374,10 @@ int bfhip_engine_read_ring_slot(bfhip_engine *e, int in_channel, int slot, void 
    thread -> butterfly maps it encodes can be checked against a model of the algorithm without a
    GPU (tests/test_wave_fft_model.py). */
 int bfhip_selftest_wave_twiddles(int log2l, int realsize, void *out, int out_bytes);
+/* tests: the nth device / pinned allocation the engine makes from now on fails with "out of
+   memory" (0: none).  tests/test_gpu_alloc_faults.py walks n over a whole engine life with it:
+   every allocation failure must come back as an error code, and destroy must still clean up. */
+int bfhip_selftest_fail_alloc(int nth);      /* returns what was left of the previous countdown */
 typedef struct bfhip_selftest_delay bfhip_selftest_delay;
 bfhip_selftest_delay *bfhip_selftest_delay_new(int fragment, int initdelay, int maxdelay, int sample_size);
 int bfhip_selftest_delay_update(bfhip_selftest_delay *d, void *buf /* fragment * sample_size bytes */, int delay);

@@ -1,0 +1,110 @@
+"""Child process of tests/test_gpu_alloc_faults.py: one engine life -- build (N:1 inputs, a
+sub-sample delay, dither, powersave, a cross-fading filter, an N-way mix, a cascade), finalize,
+blocks through the host call, a run-time scale change (private ring), a coefficient switch, the
+real-time mode with graph capture -- repeated with the n-th allocation failing, n = 1, 2, ...
+until a whole life passes without reaching the armed allocation.  Every failure has to surface
+as BfhipError (an error code), never as a crash; the engine is destroyed each time.  Prints
+"n=<k> <where it failed>" lines and a final summary line."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402  (first: it brings its own HIP runtime, tests/conftest.py)
+torch.cuda.init()
+import brutefir_amd as bf  # noqa: E402
+
+
+def free_mib():
+    torch.cuda.synchronize()
+    return torch.cuda.mem_get_info()[0] / 2 ** 20
+
+L, N = 256, 3
+rs = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+big = len(sys.argv) > 2 and sys.argv[2] == "big"      # partition length above the LDS limit
+if big:
+    L = 16384
+dt = np.float32 if rs == 4 else np.float64
+rng = np.random.default_rng(5)
+taps = [(rng.standard_normal(L * N) / 300).astype(dt) for _ in range(3)]
+x = (rng.standard_normal((L, 2)) * 2e5).astype(np.int32)
+
+
+def life(stage):
+    e = bf.Engine(L, N, rs, 3, 3)
+    try:
+        stage[0] = "setup"
+        e.map_channels(0, [0, 1, 1])
+        e.set_interleaved_phys(0, "S24_4LE", 2)
+        e.set_interleaved(1, "S16_LE")
+        e.set_maxdelay(0, 1, 300)
+        e.set_maxdelay(0, 2, 300)
+        if not big:
+            e.enable_subdelay(15, 9.0)
+            e.set_subdelay(1, 0, 37)
+            e.set_powersave(1.0)
+        e.enable_dither([1], 44100, 0)
+        stage[0] = "coeffs"
+        cs = [e.add_coeff(t) for t in taps]
+        e.add_filter(in_ch=[0], out_ch=[0], coeff=cs[0], crossfade=True)
+        e.add_filter(in_ch=[1, 2], in_scale=[0.5, 0.25], out_ch=[1], coeff=cs[1])
+        e.add_filter(in_ch=[0], out_ch=[], coeff=cs[2])
+        e.add_filter(in_f=[2], out_ch=[2], coeff=-1)
+        stage[0] = "finalize"
+        e.finalize()
+        stage[0] = "blocks"
+        for _ in range(2):
+            e.block(x)
+        stage[0] = "control"
+        e.set_scale(2, 0, 0, 0.5)          # promotes filter 2 to a private ring
+        e.set_coeff(0, cs[1])              # cross-fade
+        e.set_delay(0, 1, 123)
+        e.block(x)
+        e.update_coeff_block(cs[2], 1, taps[0][:L])
+        e.block(x)
+        stage[0] = "real-time"
+        e.rt_begin(0)
+        for _ in range(3):
+            e.rt_block(x)
+        e.rt_end()
+        e.rt_begin(bf.RT_OVERLAP)
+        e.rt_block(x)
+        e.rt_end()
+        stage[0] = "done"
+    finally:
+        left[0] = bf.lib().bfhip_selftest_fail_alloc(0)
+        e.close()
+
+
+left = [0]
+life(["warm-up"])              # module loads, LDS attributes, runtime pools
+free0 = free_mib()
+failed, absorbed, n = 0, 0, 0
+while True:
+    n += 1
+    stage = ["create"]
+    bf.lib().bfhip_selftest_fail_alloc(n)
+    try:
+        life(stage)
+        if left[0] > 0:
+            print("n=%d: a whole life makes %d allocations" % (n, n - left[0]), flush=True)
+            break
+        absorbed += 1          # reached, and handled without an error (a slab retried at half the size)
+        print("n=%d absorbed" % n, flush=True)
+    except bf.BfhipError as ex:
+        if left[0] > 0:
+            print("n=%d: error WITHOUT the armed allocation: %s" % (n, ex), flush=True)
+            sys.exit(3)
+        failed += 1
+        print("n=%d failed in %s: %s   [free %+.1f MiB]" % (n, stage[0], str(ex)[:90], free_mib() - free0), flush=True)
+    if n == 8:
+        free0 = free_mib()     # from here on (the slab retry of n = 4 shifts the runtime's own pools once)
+    if n > 600:
+        print("too many allocations", flush=True)
+        sys.exit(2)
+# and a clean life afterwards
+life(["clean"])
+drift = free0 - free_mib()
+print("SUMMARY allocations_walked=%d errors_reported=%d absorbed=%d leaked_mib=%.1f" % (n - 1, failed, absorbed, drift), flush=True)

@@ -1,0 +1,29 @@
+"""GPU: every allocation failure is an error code.  tests/helpers/alloc_faults.py (a child process:
+a crash must not take pytest down) lives one feature-rich engine life over and over with the n-th
+device / pinned allocation failing (bfhip_selftest_fail_alloc), n = 1, 2, ... until a life no
+longer reaches the armed allocation.  Each failure must surface as BfhipError, destroy must clean
+up what was half built, and a clean life must work afterwards."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("args", [["4"], ["8"], ["4", "big"]])
+def test_every_allocation_failure_is_an_error_code(hip, args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "alloc_faults.py")] + args,
+                       capture_output=True, text=True, timeout=600)
+    tail = "\n".join(r.stdout.splitlines()[-6:])
+    assert r.returncode == 0, tail + r.stderr[-1500:]
+    m = re.search(r"SUMMARY allocations_walked=(\d+) errors_reported=(\d+) absorbed=(\d+) leaked_mib=(-?[\d.]+)", r.stdout)
+    assert m, tail
+    walked, errors, absorbed = (int(g) for g in m.groups()[:3])
+    assert float(m.group(4)) < 8.0, tail                    # half-built engines give everything back
+    # every armed allocation was reached; it was reported as an error, or -- the coefficient slabs,
+    # which retry at half the size -- absorbed
+    assert walked >= 40 and errors + absorbed == walked and absorbed <= 4, tail
