@@ -22,9 +22,9 @@ PUBLIC = [os.path.join("..", "..", "include", h) for h in ("bfhip.h", "bfhip_con
 DEVICE = ["kernels.h", "fft_lds.h", "fft_wave.h", "bigfft.h"] + PUBLIC
 # translation unit -> what it includes
 UNITS = {
-    "bfhip.hip": DEVICE + ["conv_shared.h"],
+    "bfhip.hip": DEVICE + ["conv_shared.h", "alloc.h"],
     "convolver_abi.hip": DEVICE + ["conv_shared.h"],
-    "nupc.hip": DEVICE,
+    "nupc.hip": DEVICE + ["alloc.h"],
     "host_ops.cpp": ["host_fft.h", "conv_shared.h"] + PUBLIC,
 }
 

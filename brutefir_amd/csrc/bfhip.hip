@@ -28,25 +28,28 @@
 #include <tuple>
 
 #include "../../include/bfhip.h"
+#include "alloc.h"
 #include "conv_shared.h"
 #include "kernels.h"
 #include "bigfft.h"
 
 using namespace bfhip;
 
-// Every device / pinned allocation of the engine goes through these two, so that the tests can make
-// the n-th one fail (bfhip_selftest_fail_alloc) and walk every out-of-memory path there is.
+// Every device / pinned allocation of the engines goes through these (alloc.h), so that the tests
+// can make the n-th one fail (bfhip_selftest_fail_alloc) and walk every out-of-memory path there is.
 static int g_fail_alloc = 0;           // countdown: the allocation that takes it to zero fails
 static inline bool alloc_injected() { return g_fail_alloc > 0 && --g_fail_alloc == 0; }
-static hipError_t dev_alloc(void **p, size_t bytes) {
+extern "C" hipError_t bfhip_internal_dev_alloc(void **p, size_t bytes) {
     if (alloc_injected()) { *p = nullptr; return hipErrorOutOfMemory; }
     return hipMalloc(p, bytes);
 }
-template <typename P> static hipError_t dev_alloc(P **p, size_t bytes) { return dev_alloc((void **)p, bytes); }
-static hipError_t pin_alloc(void **p, size_t bytes, unsigned int flags) {
+extern "C" hipError_t bfhip_internal_pin_alloc(void **p, size_t bytes, unsigned int flags) {
     if (alloc_injected()) { *p = nullptr; return hipErrorOutOfMemory; }
     return hipHostMalloc(p, bytes, flags);
 }
+static inline hipError_t dev_alloc(void **p, size_t bytes) { return bfhip_internal_dev_alloc(p, bytes); }
+template <typename P> static hipError_t dev_alloc(P **p, size_t bytes) { return bfhip_internal_dev_alloc((void **)p, bytes); }
+static inline hipError_t pin_alloc(void **p, size_t bytes, unsigned int flags) { return bfhip_internal_pin_alloc(p, bytes, flags); }
 
 namespace {
 

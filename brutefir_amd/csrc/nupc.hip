@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "../../include/bfhip_nupc.h"
+#include "alloc.h"
 #include "kernels.h"
 
 using namespace bfhip;
@@ -125,7 +126,7 @@ struct bfhip_nupc {
     std::vector<Seg> seg;
     std::vector<bfhip_format> fmt[2];
     double safety_limit = 0;
-    bool finalized = false;
+    bool finalized = false, finalize_failed = false;
     unsigned long long block = 0;          // L0-blocks processed
     hipStream_t stream = nullptr;          // main stream: I/O, zero-slack segments, accumulate, emit
     hipEvent_t ev_in = nullptr;            // this period's frames are in the input ring
@@ -249,9 +250,19 @@ int bfhip_nupc_add_filter(bfhip_nupc *n, int in_ch, int out_ch, const void *taps
     return BFHIP_OK;
 }
 
+static int nupc_finalize_impl(bfhip_nupc *n);
+
 int bfhip_nupc_finalize(bfhip_nupc *n) {
     if (!n) return nfail(BFHIP_EINVAL, "null");
     if (n->finalized) return BFHIP_OK;
+    // half-built state is cleaned up by bfhip_nupc_destroy only: a failed finalize is not retried
+    if (n->finalize_failed) return nfail(BFHIP_ESTATE, "nupc_finalize failed before: destroy this convolver");
+    const int r = nupc_finalize_impl(n);
+    if (r != BFHIP_OK) { n->finalize_failed = true; n->finalized = false; }
+    return r;
+}
+
+static int nupc_finalize_impl(bfhip_nupc *n) {
     NCHK(hipSetDevice(n->device));
     int prio_least = 0, prio_greatest = 0;
     NCHK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
@@ -272,14 +283,14 @@ int bfhip_nupc_finalize(bfhip_nupc *n) {
     int A = 1;
     while (A < reach + L0) A <<= 1;
     n->A = A;
-    NCHK(hipMalloc(&n->d_acc, (size_t)A * n->n_out * n->rs));
+    NCHK(bfhip_internal_dev_alloc((void **)&n->d_acc, (size_t)A * n->n_out * n->rs));
     NCHK(hipMemset(n->d_acc, 0, (size_t)A * n->n_out * n->rs));
     // two periods of the longest segment: its forward transform may still be reading one while
     // the next is being filled
     n->in_frames = 2 * Lmax;
-    NCHK(hipMalloc((void **)&n->d_in, (size_t)n->in_frames * n->frame_bytes[0]));
+    NCHK(bfhip_internal_dev_alloc((void **)&n->d_in, (size_t)n->in_frames * n->frame_bytes[0]));
     NCHK(hipMemset(n->d_in, 0, (size_t)n->in_frames * n->frame_bytes[0]));
-    NCHK(hipMalloc((void **)&n->d_rawout, (size_t)L0 * n->frame_bytes[1]));
+    NCHK(bfhip_internal_dev_alloc((void **)&n->d_rawout, (size_t)L0 * n->frame_bytes[1]));
     NCHK(hipMemset(n->d_rawout, 0, (size_t)L0 * n->frame_bytes[1]));
     std::vector<DevFormat> df(n->n_out);
     std::vector<double> inv(n->n_out);
@@ -292,20 +303,20 @@ int bfhip_nupc_finalize(bfhip_nupc *n) {
         memset(&ov[ch], 0, sizeof(DevOverflow));
         ov[ch].max = f.isfloat ? 1.0 : (double)((uint64_t)1 << ((f.sbytes << 3) - 1)) - 1;
     }
-    NCHK(hipMalloc((void **)&n->d_fmt_out, df.size() * sizeof(DevFormat)));
+    NCHK(bfhip_internal_dev_alloc((void **)&n->d_fmt_out, df.size() * sizeof(DevFormat)));
     NCHK(hipMemcpy(n->d_fmt_out, df.data(), df.size() * sizeof(DevFormat), hipMemcpyHostToDevice));
-    NCHK(hipMalloc((void **)&n->d_inv_scale, inv.size() * sizeof(double)));
+    NCHK(bfhip_internal_dev_alloc((void **)&n->d_inv_scale, inv.size() * sizeof(double)));
     NCHK(hipMemcpy(n->d_inv_scale, inv.data(), inv.size() * sizeof(double), hipMemcpyHostToDevice));
-    NCHK(hipMalloc((void **)&n->d_over, ov.size() * sizeof(DevOverflow)));
+    NCHK(bfhip_internal_dev_alloc((void **)&n->d_over, ov.size() * sizeof(DevOverflow)));
     NCHK(hipMemcpy(n->d_over, ov.data(), ov.size() * sizeof(DevOverflow), hipMemcpyHostToDevice));
-    NCHK(hipMalloc((void **)&n->d_status, sizeof(int)));
+    NCHK(bfhip_internal_dev_alloc((void **)&n->d_status, sizeof(int)));
     NCHK(hipMemset(n->d_status, 0, sizeof(int)));
-    NCHK(hipMalloc((void **)&n->d_arrive, sizeof(unsigned int)));
+    NCHK(bfhip_internal_dev_alloc((void **)&n->d_arrive, sizeof(unsigned int)));
     NCHK(hipMemset(n->d_arrive, 0, sizeof(unsigned int)));
-    NCHK(hipHostMalloc((void **)&n->h_status, sizeof(int), hipHostMallocDefault));
-    NCHK(hipHostMalloc((void **)&n->h_in, (size_t)L0 * n->frame_bytes[0], hipHostMallocDefault));
-    NCHK(hipHostMalloc((void **)&n->h_out, (size_t)L0 * n->frame_bytes[1], hipHostMallocDefault));
-    NCHK(hipHostMalloc((void **)&n->h_over, (size_t)n->n_out * sizeof(DevOverflow), hipHostMallocDefault));
+    NCHK(bfhip_internal_pin_alloc((void **)&n->h_status, sizeof(int), hipHostMallocDefault));
+    NCHK(bfhip_internal_pin_alloc((void **)&n->h_in, (size_t)L0 * n->frame_bytes[0], hipHostMallocDefault));
+    NCHK(bfhip_internal_pin_alloc((void **)&n->h_out, (size_t)L0 * n->frame_bytes[1], hipHostMallocDefault));
+    NCHK(bfhip_internal_pin_alloc((void **)&n->h_over, (size_t)n->n_out * sizeof(DevOverflow), hipHostMallocDefault));
     *n->h_status = 0;
     for (auto &s : n->seg) {
         for (int ch = 0; ch < n->n_in; ch++) ECHK(bfhip_engine_set_format(s.eng, BFHIP_IN, ch, &n->fmt[0][ch]));
@@ -327,7 +338,7 @@ int bfhip_nupc_finalize(bfhip_nupc *n) {
         }
         ECHK(bfhip_engine_set_stream(s.eng, s.delay_steps > 0 ? s.stream : n->stream));
         ECHK(bfhip_engine_set_status_dev(s.eng, n->d_status));
-        NCHK(hipMalloc(&s.d_out, (size_t)s.L * n->n_out * n->rs));
+        NCHK(bfhip_internal_dev_alloc((void **)&s.d_out, (size_t)s.L * n->n_out * n->rs));
     }
     n->finalized = true;
     return BFHIP_OK;

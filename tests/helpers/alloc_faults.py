@@ -24,6 +24,7 @@ def free_mib():
 L, N = 256, 3
 rs = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 big = len(sys.argv) > 2 and sys.argv[2] == "big"      # partition length above the LDS limit
+nupc = len(sys.argv) > 2 and sys.argv[2] == "nupc"    # bfhip_nupc instead of a plain engine
 if big:
     L = 16384
 dt = np.float32 if rs == 4 else np.float64
@@ -32,7 +33,30 @@ taps = [(rng.standard_normal(L * N) / 300).astype(dt) for _ in range(3)]
 x = (rng.standard_normal((L, 2)) * 2e5).astype(np.int32)
 
 
+def nupc_life(stage):
+    """the non-uniform convolver: three segment engines + its own rings and pinned staging"""
+    n = bf.Nupc([64, 128, 256], [2, 2, 3], rs, 1, 2)
+    try:
+        stage[0] = "setup"
+        n.set_interleaved(0, "FLOAT_LE")
+        n.set_interleaved(1, "S24_4LE")
+        n.add_filter(0, 0, (rng.standard_normal(1000) / 40).astype(dt))
+        n.add_filter(0, 1, (rng.standard_normal(700) / 40).astype(dt))
+        stage[0] = "finalize"
+        n.finalize()
+        stage[0] = "blocks"
+        xs = (rng.standard_normal((64, 1)) * 0.1).astype(np.float32)
+        for _ in range(9):
+            n.block(xs)
+        stage[0] = "done"
+    finally:
+        left[0] = bf.lib().bfhip_selftest_fail_alloc(0)
+        n.close()
+
+
 def life(stage):
+    if nupc:
+        return nupc_life(stage)
     e = bf.Engine(L, N, rs, 3, 3)
     try:
         stage[0] = "setup"

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("args", [["4"], ["8"], ["4", "big"]])
+@pytest.mark.parametrize("args", [["4"], ["8"], ["4", "big"], ["4", "nupc"], ["8", "nupc"]])
 def test_every_allocation_failure_is_an_error_code(hip, args):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "alloc_faults.py")] + args,
                        capture_output=True, text=True, timeout=600)
