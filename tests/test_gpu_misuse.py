@@ -199,3 +199,40 @@ def test_degenerate_networks(hip, rs):
         e.add_filter(in_ch=[0], out_ch=[0], coeff=e.add_coeff(np.array([0.5, 0.25, -0.125, 0.0625], np.float32 if rs == 4 else np.float64)))
     y = both(tiny, 4, 1, 1, 1, n_blocks=6)
     assert y.any()
+
+
+def test_independent_engines_on_concurrent_host_threads(hip):
+    """four host threads, an engine each (different lengths, precisions and schedules), stepping at
+    the same time: the library's process-wide state (per-kernel LDS limits, twiddle tables, the
+    thread-local error text) must not get in each other's way.  ctypes drops the GIL inside every
+    call, so the calls really overlap."""
+    import threading
+    shapes = [(256, 3, 4), (1024, 2, 8), (4096, 2, 4), (64, 5, 8)]
+    results = [None] * len(shapes)
+
+    def run(k):
+        try:
+            L_, N_, rs_ = shapes[k]
+            ge, _ = cases.crossbar(hip.Engine, L_, N_, rs_, 2, 2, seed=900 + k)
+            oe, _ = cases.crossbar(bo.Engine, L_, N_, rs_, 2, 2, seed=900 + k)
+            worst = 0
+            for blk in cases.raw_blocks(40 + k, 3 * N_ + 20, L_, 2, "S24_4LE"):
+                gs, g = ge.block(blk)
+                os_, o = oe.block(blk)
+                assert gs == os_ == 0
+                worst = max(worst, int(np.abs(np.frombuffer(g.tobytes(), np.int32).astype(np.int64)
+                                              - o.view(np.int32)).max()))
+            # an error in one thread is that thread's text only
+            assert hip.lib().bfhip_engine_set_delay(ge.h, 0, 99, 0) < 0
+            assert b"set_delay" in hip.lib().bfhip_last_error()
+            results[k] = worst
+        except Exception as ex:                   # noqa: BLE001
+            results[k] = ex
+
+    threads = [threading.Thread(target=run, args=(k,)) for k in range(len(shapes))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    for k, r in enumerate(results):
+        assert isinstance(r, int) and r <= 1, (k, r)
