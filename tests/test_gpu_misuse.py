@@ -236,3 +236,55 @@ def test_independent_engines_on_concurrent_host_threads(hip):
         t.join(timeout=300)
     for k, r in enumerate(results):
         assert isinstance(r, int) and r <= 1, (k, r)
+
+
+@pytest.mark.parametrize("L_", [256, 4096])
+@pytest.mark.parametrize("fmt,rs", [("S24_4LE", 4), ("S32_LE", 4), ("FLOAT_LE", 4), ("FLOAT64_LE", 8), ("S16_LE", 4)])
+def test_samples_at_odd_byte_offsets(hip, L_, fmt, rs):
+    """frames in which the samples do not sit on their natural alignment (a header byte in front
+    of every frame): the word-sized fast paths of K1 / K3 must notice and go byte by byte"""
+    nbytes = bo.SAMPLE_FORMATS[fmt][0]
+    spacing = 3                                      # samples per frame: 2 channels + room for the skew
+    engines = []
+    for cls, mod in ((hip.Engine, hip), (bo.Engine, bo)):
+        e = cls(L_, 2, rs, 2, 2)
+        for io in (0, 1):
+            for c in range(2):
+                e.set_format(io, c, mod.make_format(fmt, spacing, 1 + c * nbytes))
+        e.in_bytes = e.out_bytes = L_ * spacing * nbytes
+        for o in range(2):
+            for i in range(2):
+                h = cases.make_ir(np.random.default_rng(70 + o * 2 + i), 2 * L_, 2)
+                e.add_filter(in_ch=[i], out_ch=[o], coeff=e.add_coeff(h.astype(np.float32 if rs == 4 else np.float64)))
+        if hasattr(e, "finalize"):
+            e.finalize()
+        engines.append(e)
+    ge, oe = engines
+    rng = np.random.default_rng(3)
+    dt = {"S24_4LE": np.int32, "S32_LE": np.int32, "FLOAT_LE": np.float32, "FLOAT64_LE": np.float64, "S16_LE": np.int16}[fmt]
+    for _ in range(4):
+        x = rng.standard_normal((L_, 2)) * 0.1
+        if fmt == "S24_4LE":
+            vals = (x * 8388608).astype(np.int32)
+        elif fmt == "S32_LE":
+            vals = (x * 2147483648.0).astype(np.int64).clip(-2**31, 2**31 - 1).astype(np.int32)
+        elif fmt == "S16_LE":
+            vals = (x * 32768).astype(np.int16)
+        else:
+            vals = x.astype(dt)
+        raw = np.zeros((L_, spacing * nbytes), np.uint8)
+        for c in range(2):
+            raw[:, 1 + c * nbytes:1 + (c + 1) * nbytes] = vals[:, c:c + 1].copy().view(np.uint8).reshape(L_, nbytes)
+        gs, g = ge.block(raw)
+        os_, o = oe.block(raw)
+        assert gs == os_ == 0
+        g = np.frombuffer(g.tobytes(), np.uint8).reshape(L_, spacing * nbytes)
+        o = np.frombuffer(o.tobytes(), np.uint8).reshape(L_, spacing * nbytes)
+        for c in range(2):
+            gv = np.ascontiguousarray(g[:, 1 + c * nbytes:1 + (c + 1) * nbytes]).view(dt).ravel()
+            ov = np.ascontiguousarray(o[:, 1 + c * nbytes:1 + (c + 1) * nbytes]).view(dt).ravel()
+            if fmt.startswith("FLOAT"):
+                assert cases.rel_rms(gv.astype(np.float64), ov.astype(np.float64)) <= (1e-5 if rs == 4 else 1e-12)
+            else:
+                lsb = 256 if fmt == "S32_LE" and rs == 4 else 1       # float32 carries 24 bits
+                assert np.abs(gv.astype(np.int64) - ov.astype(np.int64)).max() <= lsb
