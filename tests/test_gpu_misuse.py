@@ -288,3 +288,29 @@ def test_samples_at_odd_byte_offsets(hip, L_, fmt, rs):
             else:
                 lsb = 256 if fmt == "S32_LE" and rs == 4 else 1       # float32 carries 24 bits
                 assert np.abs(gv.astype(np.int64) - ov.astype(np.int64)).max() <= lsb
+
+
+@pytest.mark.parametrize("L_", [512, 8192])
+def test_device_buffers_that_are_only_sample_aligned(hip, L_):
+    """bfhip_engine_block_dev with raw buffers that start 4 bytes into an allocation (a slice of
+    somebody's larger buffer): nothing may assume 16-byte alignment of the caller's pointers"""
+    import torch
+    dev = torch.device("cuda", 0)
+    I_, O_ = 3, 2
+    ge, _ = cases.crossbar(hip.Engine, L_, 2, 4, I_, O_, "S24_4LE", "S24_4LE", seed=31)
+    oe, _ = cases.crossbar(bo.Engine, L_, 2, 4, I_, O_, "S24_4LE", "S24_4LE", seed=31)
+    big_in = torch.zeros(L_ * I_ + 8, dtype=torch.int32, device=dev)
+    big_out = torch.zeros(L_ * O_ + 8, dtype=torch.int32, device=dev)
+    for off in (1, 3):
+        big_out.zero_()
+        vin = big_in[off:off + L_ * I_]
+        vout = big_out[off:off + L_ * O_]
+        assert vin.data_ptr() % 16 != 0
+        for blk in cases.raw_blocks(50 + off, 4, L_, I_, "S24_4LE"):
+            vin.copy_(torch.from_numpy(blk.reshape(-1)).to(dev))
+            torch.cuda.synchronize()
+            ge.block_dev(vin, vout)
+            assert ge.sync() == 0
+            _, o = oe.block(blk)
+            assert np.abs(vout.cpu().numpy().astype(np.int64) - o.view(np.int32)).max() <= 1
+        assert int(big_out[:off].abs().sum()) == 0 and int(big_out[off + L_ * O_:].abs().sum()) == 0   # nothing outside
