@@ -314,3 +314,40 @@ def test_device_buffers_that_are_only_sample_aligned(hip, L_):
             _, o = oe.block(blk)
             assert np.abs(vout.cpu().numpy().astype(np.int64) - o.view(np.int32)).max() <= 1
         assert int(big_out[:off].abs().sum()) == 0 and int(big_out[off + L_ * O_:].abs().sum()) == 0   # nothing outside
+
+
+@pytest.mark.parametrize("I_,O_", [(300, 2), (2, 300), (130, 130)])
+def test_very_wide_and_very_tall_crossbars(hip, I_, O_):
+    """hundreds of channels on one side (more than BF_MAXCHANNELS = 256 even): output groups of 8
+    with hundreds of entries, hundreds of groups with one entry; (130, 130) as one-to-one filters
+    plus a few mixes"""
+    L_, N_ = 128, 2
+    engines = []
+    for cls in (hip.Engine, bo.Engine):
+        e = cls(L_, N_, 4, I_, O_)
+        e.set_interleaved(0, "S16_LE")
+        e.set_interleaved(1, "FLOAT_LE")
+        rng = np.random.default_rng(11)
+        if I_ == O_:
+            for c in range(I_):
+                h = cases.make_ir(rng, L_ * N_, 2).astype(np.float32)
+                e.add_filter(in_ch=[c], out_ch=[c], coeff=e.add_coeff(h))
+            for c in range(0, I_, 17):
+                h = cases.make_ir(rng, L_ * N_, 4).astype(np.float32)
+                e.add_filter(in_ch=[c, (c + 5) % I_], in_scale=[0.5, -0.5], out_ch=[(c + 1) % O_], coeff=e.add_coeff(h))
+        else:
+            hs = [e.add_coeff(cases.make_ir(rng, L_ * N_, max(I_, 2)).astype(np.float32)) for _ in range(7)]
+            k = 0
+            for o in range(O_):
+                for i in range(I_):
+                    e.add_filter(in_ch=[i], out_ch=[o], coeff=hs[k % 7], in_scale=[1.0 + 0.01 * (k % 5)])
+                    k += 1
+        if hasattr(e, "finalize"):
+            e.finalize()
+        engines.append(e)
+    ge, oe = engines
+    for blk in cases.raw_blocks(2, N_ + 3, L_, I_, "S16_LE", amplitude=0.2):
+        gs, g = ge.block(blk)
+        os_, o = oe.block(blk)
+        assert gs == os_ == 0
+        assert cases.rel_rms(cases.samples(g, "FLOAT_LE"), cases.samples(o, "FLOAT_LE")) <= 1e-5
