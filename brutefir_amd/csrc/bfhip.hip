@@ -11,6 +11,7 @@
 // The integer bookkeeping (slot = blockcounter mod N, delay clamp, cblocks truncation,
 // warm-up count) follows bfrun.c:1566-1600,1745-1746 literally.
 #include <hip/hip_runtime.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <array>
@@ -233,6 +234,7 @@ struct DelayLine {
 
 struct bfhip_engine {
     int device = 0;
+    pid_t owner = 0;               // the process that created the engine (HIP state does not survive fork())
     int L = 0, N = 0, rs = 4, log2L = 0;
     int n_ch[2] = {0, 0};
     std::vector<bfhip_format> fmt[2];
@@ -1405,9 +1407,20 @@ int flush_pending(bfhip_engine *e) {
     return BFHIP_OK;
 }
 
+// An engine is usable in the process that created it only: a fork()ed child inherits the handle but
+// not a working HIP runtime, and its first device call would hang.  Checked before anything else.
+int check_owner(const bfhip_engine *e) {
+    if (e->owner != getpid())
+        return fail(BFHIP_ESTATE, "this engine belongs to process %d: HIP state does not survive fork(); create the "
+                    "engine in the process that runs the blocks", (int)e->owner);
+    return BFHIP_OK;
+}
+
 int ensure_ready(bfhip_engine *e) {
     if (!e) return fail(BFHIP_EINVAL, "null engine");
+    { const int ro = check_owner(e); if (ro != BFHIP_OK) return ro; }
     if (!e->finalized) return fail(BFHIP_ESTATE, "engine not finalized");
+    { const int ro = check_owner(e); if (ro != BFHIP_OK) return ro; }
     HIPCHK(hipSetDevice(e->device));
     if (e->plan_dirty && !e->pendq.empty()) {
         // the owed output belongs to the old plan's geometry and buffers
@@ -1896,6 +1909,7 @@ bfhip_engine *bfhip_engine_create(int device, int length, int n_blocks, int real
 
     bfhip_engine *e = new bfhip_engine();
     e->device = device; e->L = length; e->N = n_blocks; e->rs = realsize; e->log2L = lg;
+    e->owner = getpid();
     e->big = lg > BIG_LOG2M;
     e->big_R = e->big ? length / BIG_M : 1;
     e->n_ch[0] = n_in; e->n_ch[1] = n_out;
@@ -1958,6 +1972,7 @@ bfhip_engine *bfhip_engine_create(int device, int length, int n_blocks, int real
 
 void bfhip_engine_destroy(bfhip_engine *e) {
     if (e == nullptr) return;
+    if (e->owner != getpid()) { delete e; return; }     // a forked child: the device objects are the parent's
     (void)hipSetDevice(e->device);
     e->pendq.clear();
     (void)sync_all(e);
@@ -2146,6 +2161,7 @@ static int dither_upload(bfhip_engine *e) {
 static int add_coeff_common(bfhip_engine *e, const void *taps, bool on_device, int n_taps,
                             double scale, int n_blocks) {
     if (!e || (!taps && n_taps > 0) || n_taps < 0) return fail(BFHIP_EINVAL, "add_coeff: bad argument");
+    { const int ro = check_owner(e); if (ro != BFHIP_OK) return ro; }
     HIPCHK(hipSetDevice(e->device));
     const int L = e->L;
     if (n_blocks <= 0) n_blocks = (n_taps + L - 1) / L;
@@ -2193,6 +2209,7 @@ static int add_coeff_common(bfhip_engine *e, const void *taps, bool on_device, i
 int bfhip_engine_reserve_coeffs(bfhip_engine *e, double total_bytes) {
     if (!e || total_bytes < 0) return fail(BFHIP_EINVAL, "reserve_coeffs: bad argument");
     if (!e->coeff_arena || total_bytes == 0) return BFHIP_OK;
+    { const int ro = check_owner(e); if (ro != BFHIP_OK) return ro; }
     HIPCHK(hipSetDevice(e->device));
     // every set is rounded up to 64 KiB: leave room for that
     const size_t want = ((size_t)(total_bytes * 1.05) + ((size_t)1 << 20) + 65535) & ~(size_t)65535;
@@ -2245,6 +2262,7 @@ int bfhip_engine_add_coeff_processed_blocks(bfhip_engine *e, void *const cbufs[]
     if (!e || !cbufs || n_blocks < 1) return fail(BFHIP_EINVAL, "add_coeff_processed_blocks: bad argument");
     if (n_blocks > e->N) return fail(BFHIP_EINVAL, "coefficient set has %d blocks, engine has %d", n_blocks, e->N);
     for (int b = 0; b < n_blocks; b++) if (!cbufs[b]) return fail(BFHIP_EINVAL, "add_coeff_processed_blocks: block %d is NULL", b);
+    { const int ro = check_owner(e); if (ro != BFHIP_OK) return ro; }
     HIPCHK(hipSetDevice(e->device));
     Coeff c;
     c.n_blocks = n_blocks;
@@ -2274,12 +2292,14 @@ int bfhip_engine_refresh_coeff_processed(bfhip_engine *e, int coeff, int block, 
         if (c.watch_src.empty()) return fail(BFHIP_EINVAL, "refresh_coeff_processed: no host buffer known for this set");
         cbuf = c.watch_src[block];
     }
+    { const int ro = check_owner(e); if (ro != BFHIP_OK) return ro; }
     HIPCHK(hipSetDevice(e->device));
     return upload_processed_block(e, c, block, cbuf);
 }
 
 int bfhip_engine_poll_coeff_changes(bfhip_engine *e) {
     if (!e) return fail(BFHIP_EINVAL, "null engine");
+    { const int ro = check_owner(e); if (ro != BFHIP_OK) return ro; }
     HIPCHK(hipSetDevice(e->device));
     return poll_coeff_changes(e);
 }
@@ -2287,6 +2307,7 @@ int bfhip_engine_poll_coeff_changes(bfhip_engine *e) {
 int bfhip_engine_add_coeff_processed(bfhip_engine *e, const void *cbufs, int n_blocks) {
     if (!e || !cbufs || n_blocks < 1) return fail(BFHIP_EINVAL, "add_coeff_processed: bad argument");
     if (n_blocks > e->N) return fail(BFHIP_EINVAL, "coefficient set has %d blocks, engine has %d", n_blocks, e->N);
+    { const int ro = check_owner(e); if (ro != BFHIP_OK) return ro; }
     HIPCHK(hipSetDevice(e->device));
     const size_t n = (size_t)n_blocks * 2 * e->L;
     // convolver_verify_cbuf (fftw_convolver.c:598-622) as load_coeff applies it (bfconf.c:1958)
@@ -2319,6 +2340,7 @@ int bfhip_engine_add_coeff_processed(bfhip_engine *e, const void *cbufs, int n_b
 
 int bfhip_engine_read_coeff_processed(bfhip_engine *e, int coeff, void *cbufs) {
     if (!e || !cbufs || coeff < 0 || coeff >= (int)e->coeffs.size()) return fail(BFHIP_EINVAL, "read_coeff_processed: bad argument");
+    { const int ro = check_owner(e); if (ro != BFHIP_OK) return ro; }
     HIPCHK(hipSetDevice(e->device));
     const int nb = e->coeffs[coeff].n_blocks;
     const size_t bytes = (size_t)nb * 2 * e->L * e->rs;
@@ -2342,6 +2364,7 @@ int bfhip_engine_update_coeff_block(bfhip_engine *e, int coeff, int block, const
     if (!e || coeff < 0 || coeff >= (int)e->coeffs.size() || block < 0 ||
         block >= e->coeffs[coeff].n_blocks || !taps)
         return fail(BFHIP_EINVAL, "update_coeff_block: bad argument");
+    { const int ro = check_owner(e); if (ro != BFHIP_OK) return ro; }
     HIPCHK(hipSetDevice(e->device));
     const size_t bytes = (size_t)e->L * e->rs;
     if (bytes > e->taps_cap) {
@@ -2402,12 +2425,14 @@ int bfhip_engine_finalize(bfhip_engine *e) {
     // a finalize that failed half way (out of device memory, a bad coefficient set) leaves partial
     // state behind that only bfhip_engine_destroy cleans up: it is not retried
     if (e->finalize_failed) return fail(BFHIP_ESTATE, "finalize failed before: destroy this engine");
+    { const int ro = check_owner(e); if (ro != BFHIP_OK) return ro; }
     const int r = finalize_impl(e);
     if (r != BFHIP_OK) { e->finalize_failed = true; e->finalized = false; }
     return r;
 }
 
 static int finalize_impl(bfhip_engine *e) {
+    { const int ro = check_owner(e); if (ro != BFHIP_OK) return ro; }
     HIPCHK(hipSetDevice(e->device));
     const size_t L = e->L;
     const size_t prev_b = (size_t)e->n_ch[0] * L * e->rs;
@@ -2639,6 +2664,7 @@ static int finalize_impl(bfhip_engine *e) {
 static int promote_filter(bfhip_engine *e, int fi) {
     if (!e->finalized || e->owner_index[fi] >= 0 || e->promoted[fi]) return BFHIP_OK;
     const Filter &f = e->filters[fi];
+    { const int ro = check_owner(e); if (ro != BFHIP_OK) return ro; }
     HIPCHK(hipSetDevice(e->device));
     const size_t bytes = (size_t)e->N * e->L * e->csize();
     void *ring = nullptr;
@@ -2925,6 +2951,7 @@ static int block_dev_impl(bfhip_engine *e, const void *rawin_dev, void *rawout_d
 
 int bfhip_engine_flush(bfhip_engine *e) {
     if (!e || !e->finalized) return fail(BFHIP_ESTATE, "engine not finalized");
+    { const int ro = check_owner(e); if (ro != BFHIP_OK) return ro; }
     HIPCHK(hipSetDevice(e->device));
     return flush_pending(e);
 }
@@ -2936,6 +2963,7 @@ int bfhip_engine_output_lag(const bfhip_engine *e) {
 
 int bfhip_engine_sync(bfhip_engine *e) {
     if (!e || !e->finalized) return fail(BFHIP_ESTATE, "engine not finalized");
+    { const int ro = check_owner(e); if (ro != BFHIP_OK) return ro; }
     HIPCHK(hipSetDevice(e->device));
     { int _r = flush_pending(e); if (_r != BFHIP_OK) return _r; }
     { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
@@ -3004,6 +3032,7 @@ int bfhip_engine_rt_begin(bfhip_engine *e, int flags) {
 int bfhip_engine_rt_end(bfhip_engine *e) {
     if (!e) return fail(BFHIP_EINVAL, "null engine");
     if (!e->rt.on) return BFHIP_OK;
+    { const int ro = check_owner(e); if (ro != BFHIP_OK) return ro; }
     HIPCHK(hipSetDevice(e->device));
     { int r = sync_all(e); if (r != BFHIP_OK) return r; }
     rt_release(e);
@@ -3058,6 +3087,7 @@ int bfhip_engine_rt_wait(bfhip_engine *e, void *rawout, bfhip_overflow overflow[
     auto &rt = e->rt;
     if (rt.submitted == rt.waited) return fail(BFHIP_ESTATE, "rt_wait: nothing in flight");
     const int p = (int)(rt.waited & 1);
+    { const int ro = check_owner(e); if (ro != BFHIP_OK) return ro; }
     HIPCHK(hipSetDevice(e->device));
     if ((rt.flags & BFHIP_RT_SPIN) && !(rt.flags & BFHIP_RT_OVERLAP)) {
         // the tail kernel's last store is the sequence word: watch it from the CPU; after 2 ms
@@ -3159,6 +3189,7 @@ int bfhip_engine_prewarm(bfhip_engine *e) {
 
 int bfhip_engine_set_status_dev(bfhip_engine *e, int *status_dev) {
     if (!e || !e->finalized) return fail(BFHIP_ESTATE, "set_status_dev: engine not finalized");
+    { const int ro = check_owner(e); if (ro != BFHIP_OK) return ro; }
     HIPCHK(hipSetDevice(e->device));
     { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
     if (!e->d_status_own) e->d_status_own = e->d_status;
@@ -3169,6 +3200,7 @@ int bfhip_engine_set_status_dev(bfhip_engine *e, int *status_dev) {
 
 int bfhip_engine_set_stream(bfhip_engine *e, void *hip_stream) {
     if (!e) return fail(BFHIP_EINVAL, "null engine");
+    { const int ro = check_owner(e); if (ro != BFHIP_OK) return ro; }
     HIPCHK(hipSetDevice(e->device));
     if (e->finalized) { int _r = flush_pending(e); if (_r != BFHIP_OK) return _r; }
     { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
@@ -3181,6 +3213,7 @@ int bfhip_engine_set_stream(bfhip_engine *e, void *hip_stream) {
 
 int bfhip_engine_get_overflow(bfhip_engine *e, int ch, bfhip_overflow *of) {
     if (!e || !e->finalized || ch < 0 || ch >= e->n_ch[1] || !of) return fail(BFHIP_EINVAL, "get_overflow: bad argument");
+    { const int ro = check_owner(e); if (ro != BFHIP_OK) return ro; }
     HIPCHK(hipSetDevice(e->device));
     { int _r = flush_pending(e); if (_r != BFHIP_OK) return _r; }
     { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
@@ -3190,6 +3223,7 @@ int bfhip_engine_get_overflow(bfhip_engine *e, int ch, bfhip_overflow *of) {
 
 int bfhip_engine_reset_overflow(bfhip_engine *e) {
     if (!e || !e->finalized) return fail(BFHIP_ESTATE, "engine not finalized");
+    { const int ro = check_owner(e); if (ro != BFHIP_OK) return ro; }
     HIPCHK(hipSetDevice(e->device));
     std::vector<DevOverflow> v(e->n_ch[1]);
     for (int c = 0; c < e->n_ch[1]; c++) {
@@ -3213,6 +3247,7 @@ int bfhip_engine_ring_depth(const bfhip_engine *e) { return e ? e->R : 0; }
 
 int bfhip_engine_enable_timing(bfhip_engine *e, int on) {
     if (!e) return fail(BFHIP_EINVAL, "null engine");
+    { const int ro = check_owner(e); if (ro != BFHIP_OK) return ro; }
     HIPCHK(hipSetDevice(e->device));
     if (on && e->ev.empty()) {
         e->ev.resize((size_t)MAX_TIMED * 6);
@@ -3230,6 +3265,7 @@ int bfhip_engine_enable_timing(bfhip_engine *e, int on) {
 
 int bfhip_engine_get_timing(bfhip_engine *e, double ms[4]) {
     if (!e || !ms) return fail(BFHIP_EINVAL, "get_timing: bad argument");
+    { const int ro = check_owner(e); if (ro != BFHIP_OK) return ro; }
     HIPCHK(hipSetDevice(e->device));
     { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
     ms[0] = ms[1] = ms[2] = ms[3] = 0;
@@ -3260,6 +3296,7 @@ int bfhip_engine_algorithmic_bytes(bfhip_engine *e, double bytes[2]) {
 
 int bfhip_engine_read_output_spectrum(bfhip_engine *e, int ch, void *dst) {
     if (!e || !e->finalized || ch < 0 || ch >= e->n_ch[1] || !dst) return fail(BFHIP_EINVAL, "read_output_spectrum: bad argument");
+    { const int ro = check_owner(e); if (ro != BFHIP_OK) return ro; }
     HIPCHK(hipSetDevice(e->device));
     { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
     const size_t row = (size_t)e->L * e->csize();
@@ -3281,6 +3318,7 @@ int bfhip_engine_read_output_spectrum(bfhip_engine *e, int ch, void *dst) {
 
 int bfhip_engine_read_ring_slot(bfhip_engine *e, int ch, int slot, void *dst) {
     if (!e || !e->finalized || ch < 0 || ch >= e->n_ch[0] || slot < 0 || slot >= e->R || !dst) return fail(BFHIP_EINVAL, "read_ring_slot: bad argument");
+    { const int ro = check_owner(e); if (ro != BFHIP_OK) return ro; }
     HIPCHK(hipSetDevice(e->device));
     { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
     const size_t row = (size_t)e->L * e->csize();

@@ -88,7 +88,9 @@ const char *bfhip_version(void);
    n_blocks = N partitions per filter, realsize 4 or 8.
    The device is initialised here: call it in the forked filter process, never in the parent
    (nothing the parent needs -- convolver_init, convolver_coeffs2cbuf, ... -- touches
-   the device). */
+   the device).  An engine belongs to the process that created it: in a fork()ed child every
+   device entry point returns BFHIP_ESTATE (before any HIP call, which would hang in the inherited
+   runtime), and bfhip_engine_destroy only frees the child's copy of the handle. */
 bfhip_engine *bfhip_engine_create(int device, int length, int n_blocks, int realsize,
                                   int n_in, int n_out);
 void bfhip_engine_destroy(bfhip_engine *e);

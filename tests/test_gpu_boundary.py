@@ -601,3 +601,48 @@ def test_coefficient_slabs_reserve_overflow_and_error_paths(hip, monkeypatch):
                 {"BFHIP_COEFF_PAD_B": "r"}):
         got = run(env)
         assert all(np.array_equal(a, b) for a, b in zip(base, got)), env
+
+
+def test_engine_in_a_forked_child_is_refused_not_hung(hip):
+    """include/bfhip.h: an engine lives in the process that created it.  A fork()ed child that
+    inherits the handle gets BFHIP_ESTATE from every device entry point -- before any HIP call,
+    which would hang in the inherited runtime -- may destroy its copy of the handle, and the
+    parent's engine is unaffected.  (Fresh interpreter: os.fork in the pytest process would
+    duplicate pytest.)"""
+    code = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import brutefir_amd as bf
+import cases
+e, _ = cases.crossbar(bf.Engine, 256, 2, 4, 2, 2)
+blk = cases.raw_blocks(1, 3, 256, 2, "S24_4LE")
+st, first = e.block(blk[0])
+r, w = os.pipe()
+pid = os.fork()
+if pid == 0:
+    msgs = []
+    for call in (lambda: e.block(blk[1]), lambda: e.sync(), lambda: e.add_coeff(np.ones(4, np.float32)),
+                 lambda: e.overflow(0), lambda: e.rt_begin(0)):
+        try:
+            call()
+            msgs.append("NO ERROR")
+        except bf.BfhipError as ex:
+            msgs.append("refused" if "belongs to process" in str(ex) else "OTHER: " + str(ex))
+    e.close()                                  # frees the child's copy of the handle, touches no device object
+    os.write(w, ";".join(msgs).encode())
+    os._exit(0)
+os.close(w)
+got = os.read(r, 4096).decode()
+_, status = os.waitpid(pid, 0)
+print("child:", got, "exit", status)
+st2, second = e.block(blk[1])                  # the parent goes on as if nothing had happened
+ref, _ = cases.crossbar(bf.Engine, 256, 2, 4, 2, 2)
+ref.block(blk[0])
+st3, want = ref.block(blk[1])
+assert st == st2 == st3 == 0 and np.array_equal(second, want)
+assert got == ";".join(["refused"] * 5) and status == 0, got
+print("PARENT OK")
+''' % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and "PARENT OK" in r.stdout, r.stdout + r.stderr[-2000:]
