@@ -22,6 +22,7 @@
 // it in the period its first output frame is due.  So the worst period costs about as much
 // as the common one, which is what real-time use needs.
 #include <hip/hip_runtime.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -99,6 +100,12 @@ int nfail(int code, const std::string &msg) { n_err = msg; (void)hipGetLastError
         if (_e != hipSuccess) return nfail(BFHIP_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
     } while (0)
 
+#define OWNER(n)                                                                            \
+    do {                                                                                    \
+        if ((n)->owner != getpid())                                                         \
+            return nfail(BFHIP_ESTATE, "this convolver belongs to another process: HIP state does not survive fork()"); \
+    } while (0)
+
 #define ECHK(expr)                                                                          \
     do {                                                                                    \
         int _r = (expr);                                                                    \
@@ -123,6 +130,7 @@ struct Seg {
 
 struct bfhip_nupc {
     int device = 0, rs = 4, n_in = 0, n_out = 0;
+    pid_t owner = 0;                       // like an engine, it lives in the process that created it
     std::vector<Seg> seg;
     std::vector<bfhip_format> fmt[2];
     double safety_limit = 0;
@@ -156,6 +164,7 @@ bfhip_nupc *bfhip_nupc_create(int device, int realsize, int n_in, int n_out, int
     if (n_segments < 1 || !seg_length || !seg_blocks || n_in < 1 || n_out < 1) { nfail(BFHIP_EINVAL, "nupc_create: bad argument"); return nullptr; }
     bfhip_nupc *n = new bfhip_nupc();
     n->device = device; n->rs = realsize; n->n_in = n_in; n->n_out = n_out;
+    n->owner = getpid();
     long off = 0;
     for (int k = 0; k < n_segments; k++) {
         Seg s;
@@ -192,6 +201,7 @@ bfhip_nupc *bfhip_nupc_create(int device, int realsize, int n_in, int n_out, int
 
 void bfhip_nupc_destroy(bfhip_nupc *n) {
     if (!n) return;
+    if (n->owner != getpid()) { for (auto &sg : n->seg) if (sg.eng) bfhip_engine_destroy(sg.eng); delete n; return; }   // a forked child
     (void)hipSetDevice(n->device);
     if (n->stream) (void)hipStreamSynchronize(n->stream);
     for (auto &s : n->seg) if (s.stream) (void)hipStreamSynchronize(s.stream);
@@ -263,6 +273,7 @@ int bfhip_nupc_finalize(bfhip_nupc *n) {
 }
 
 static int nupc_finalize_impl(bfhip_nupc *n) {
+    OWNER(n);
     NCHK(hipSetDevice(n->device));
     int prio_least = 0, prio_greatest = 0;
     NCHK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
@@ -368,6 +379,7 @@ extern "C" {
 int bfhip_nupc_block_dev(bfhip_nupc *n, const void *rawin_dev, void *rawout_dev) {
     if (!n || !n->finalized) return nfail(BFHIP_ESTATE, "nupc not finalized");
     if (!rawin_dev || !rawout_dev) return nfail(BFHIP_EINVAL, "nupc_block_dev: null buffer");
+    OWNER(n);
     NCHK(hipSetDevice(n->device));
     const int L0 = n->seg[0].L;
     const unsigned long long end = (n->block + 1) * (unsigned long long)L0;       // samples received
@@ -421,6 +433,7 @@ int bfhip_nupc_block_dev(bfhip_nupc *n, const void *rawin_dev, void *rawout_dev)
 // yet) and returns the status bits collected since the last call
 int bfhip_nupc_sync(bfhip_nupc *n) {
     if (!n || !n->finalized) return nfail(BFHIP_ESTATE, "nupc not finalized");
+    OWNER(n);
     NCHK(hipSetDevice(n->device));
     NCHK(hipStreamSynchronize(n->stream));
     const int st = *(volatile int *)n->h_status;
@@ -431,6 +444,7 @@ int bfhip_nupc_sync(bfhip_nupc *n) {
 // host buffers: copies in, runs, copies out, waits; returns status bits
 int bfhip_nupc_block(bfhip_nupc *n, const void *rawin, void *rawout, bfhip_overflow overflow[]) {
     if (!n || !n->finalized || !rawin || !rawout) return nfail(BFHIP_ESTATE, "nupc_block: bad state or argument");
+    OWNER(n);
     NCHK(hipSetDevice(n->device));
     const int L0 = n->seg[0].L;
     // upload straight into this block's slot of the input ring
@@ -457,6 +471,7 @@ int bfhip_nupc_block(bfhip_nupc *n, const void *rawin, void *rawout, bfhip_overf
 
 int bfhip_nupc_get_overflow(bfhip_nupc *n, int ch, bfhip_overflow *of) {
     if (!n || !n->finalized || !of || ch < 0 || ch >= n->n_out) return nfail(BFHIP_EINVAL, "nupc_get_overflow: bad argument");
+    OWNER(n);
     NCHK(hipSetDevice(n->device));
     NCHK(hipStreamSynchronize(n->stream));
     NCHK(hipMemcpy(of, n->d_over + ch, sizeof(DevOverflow), hipMemcpyDeviceToHost));
