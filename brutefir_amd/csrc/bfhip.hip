@@ -65,8 +65,10 @@ int fail(int code, const char *fmt, ...) {
     g_err = buf;
     // a failed runtime call (an allocation that did not fit, say) leaves its code behind as the
     // "last error"; reported here, it must not be found again by the launch check of a later,
-    // unrelated call
-    (void)hipGetLastError();
+    // unrelated call.  Only the two codes a runtime failure is reported under reach the runtime:
+    // argument and state errors (a NULL handle, the fork()ed-child refusal of check_owner) return
+    // without a single HIP call.
+    if (code == BFHIP_EHIP || code == BFHIP_ENOMEM) (void)hipGetLastError();
     return code;
 }
 
@@ -897,6 +899,8 @@ int cblocks_of(const bfhip_engine *e, int coeff, int delay) {   // bfrun.c:1585-
 // uniform crossbar: every entry OG coefficient terms of the same length, no split entries, every
 // chunk the same number of entries, no idle blocks in the grid.  Entries whose OG sets did not
 // change since the last build are left alone (scale changes rebuild the plan, not the data).
+const void *const STREAM_KEY_STALE = (const void *)(uintptr_t)1;     // never a set's address
+
 template <typename T>
 int build_stream_layout(bfhip_engine *e, const std::vector<MacEntry<T>> &flat, const std::vector<ChunkRange> &chunks,
                         int S, double bytes_H) {
@@ -973,7 +977,15 @@ int build_stream_layout(bfhip_engine *e, const std::vector<MacEntry<T>> &flat, c
 // set): bring the stream-ordered copy up to date
 template <typename T>
 int stream_refresh_block(bfhip_engine *e, const void *H, int block) {
-    if (e->hstream.base == nullptr || e->plan_dirty) return BFHIP_OK;       // a dirty plan is rebuilt (and compared) anyway
+    if (e->hstream.base == nullptr || e->plan_dirty) {
+        // no copy now (the plan is about to be rebuilt, or this block runs without the stream-ordered
+        // copy: a cross-fade block).  The rebuild compares entries by their set POINTERS, which an
+        // in-place rewrite does not change: forget that these entries hold H, so that the next
+        // build_stream_layout lays them out again from the new data.
+        for (auto &k : e->stream_keys)
+            for (int j = 0; j < OG; j++) if (k[j] == H) k[j] = STREAM_KEY_STALE;
+        return BFHIP_OK;
+    }
     std::vector<int> hit;
     for (size_t i = 0; i < e->stream_keys.size(); i++)
         for (int j = 0; j < OG; j++) if (e->stream_keys[i][j] == H) { hit.push_back((int)i); break; }
@@ -1382,19 +1394,30 @@ int poll_coeff_changes(bfhip_engine *e);
 int do_outputs(bfhip_engine *e, const void *Zp, size_t chunk_stride, int n_chunks, int first,
                int count, void *rawout_dev);
 
+// restores "the next launch goes to the main stream" on every return path of a schedule that sends
+// launches to a side stream (an error in the middle must not leave e->ls pointing there: the do_*
+// helpers of the phase entry points launch on e->ls)
+struct LsGuard {
+    bfhip_engine *e;
+    ~LsGuard() { e->ls = e->stream; }
+};
+
 // the inverse transforms of the blocks whose output is still owed (deferred output: one, ping-pong
 // schedule: up to two), oldest first, each as a launch of its own
 int flush_pending(bfhip_engine *e) {
+    LsGuard guard{e};                  // every return path leaves the launch stream on the main stream
     const bool side = e->pipe2 && !e->pendq.empty();
     while (!e->pendq.empty()) {
+        // (popped only once its launch is in the stream: a failed launch leaves the owed output
+        // queued -- the caller sees the error, and the entry's event is never silently dropped)
         const bfhip_engine::Pending p = e->pendq.front();
-        e->pendq.pop_front();
         // the ping-pong schedule keeps every output pass on the side stream (their overflow state
         // and the dither chains are sequential), behind the MAC that produced the spectra
         e->ls = e->pipe2 ? e->s_in : e->stream;
         if (p.mac_done) HIPCHK(hipStreamWaitEvent(e->ls, p.mac_done, 0));
         const int r = do_outputs(e, p.Zp, p.chunk_stride, p.n_chunks, 0, e->n_ch[1], p.rawout);
-        if (r != BFHIP_OK) { e->ls = e->stream; return r; }
+        if (r != BFHIP_OK) return r;
+        e->pendq.pop_front();
         if (p.out_done) HIPCHK(hipEventRecord(p.out_done, e->ls));
     }
     e->ls = e->stream;
@@ -1420,7 +1443,6 @@ int ensure_ready(bfhip_engine *e) {
     if (!e) return fail(BFHIP_EINVAL, "null engine");
     { const int ro = check_owner(e); if (ro != BFHIP_OK) return ro; }
     if (!e->finalized) return fail(BFHIP_ESTATE, "engine not finalized");
-    { const int ro = check_owner(e); if (ro != BFHIP_OK) return ro; }
     HIPCHK(hipSetDevice(e->device));
     if (e->plan_dirty && !e->pendq.empty()) {
         // the owed output belongs to the old plan's geometry and buffers
@@ -2826,6 +2848,7 @@ static int block_dev_impl(bfhip_engine *e, const void *rawin_dev, void *rawout_d
     const int buf = (int)(e->blocks_done & 1);
     void *Zp = ((pipe || e->defer_out) && buf) ? e->d_Zp2 : e->d_Zp;
     timing_begin(e);
+    LsGuard guard{e};
 
     if (e->pipe2) {
         // side stream: [K3 of block t-2 | K1 of block t]; main stream: MAC of block t behind it.  The
@@ -2837,8 +2860,7 @@ static int block_dev_impl(bfhip_engine *e, const void *rawin_dev, void *rawout_d
         if (in_ready) HIPCHK(hipStreamWaitEvent(e->s_in, in_ready, 0));
         if ((r = record(e, 0)) != BFHIP_OK) return r;
         if (e->pendq.size() >= 2) {
-            const bfhip_engine::Pending p = e->pendq.front();
-            e->pendq.pop_front();
+            const bfhip_engine::Pending p = e->pendq.front();     // popped once its launch is in the stream
             HIPCHK(hipStreamWaitEvent(e->s_in, p.mac_done, 0));
             if (p.n_chunks <= 2) {
                 hipError_t err = hipSuccess;
@@ -2846,8 +2868,10 @@ static int block_dev_impl(bfhip_engine *e, const void *rawin_dev, void *rawout_d
                 DISPATCH_WAVE(launch_io_wave, e, p.Zp, p.chunk_stride, p.n_chunks, 0, e->n_ch[1],
                               (uint8_t *)p.rawout, (const uint8_t *)rawin_dev, slot, &err)
                 if (err != hipSuccess) return fail(BFHIP_EHIP, "io launch: %s", hipGetErrorString(err));
+                e->pendq.pop_front();
             } else {
                 if ((r = do_outputs(e, p.Zp, p.chunk_stride, p.n_chunks, 0, e->n_ch[1], p.rawout)) != BFHIP_OK) return r;
+                e->pendq.pop_front();
                 if ((r = do_inputs(e, rawin_dev)) != BFHIP_OK) return r;
             }
             if (p.out_done) HIPCHK(hipEventRecord(p.out_done, e->s_in));
@@ -2886,13 +2910,13 @@ static int block_dev_impl(bfhip_engine *e, const void *rawin_dev, void *rawout_d
         if (in_ready) HIPCHK(hipStreamWaitEvent(e->stream, in_ready, 0));
         if ((r = record(e, 0)) != BFHIP_OK) return r;
         if (!e->pendq.empty() && e->pendq.front().n_chunks <= 2) {
-            const bfhip_engine::Pending p = e->pendq.front();
-            e->pendq.pop_front();
+            const bfhip_engine::Pending p = e->pendq.front();     // popped once its launch is in the stream
             hipError_t err = hipSuccess;
             const int slot = (int)(e->blockcounter % (unsigned int)e->R);
             DISPATCH_WAVE(launch_io_wave, e, p.Zp, p.chunk_stride, p.n_chunks, 0, e->n_ch[1],
                           (uint8_t *)p.rawout, (const uint8_t *)rawin_dev, slot, &err)
             if (err != hipSuccess) return fail(BFHIP_EHIP, "io launch: %s", hipGetErrorString(err));
+            e->pendq.pop_front();
             if (p.out_done) HIPCHK(hipEventRecord(p.out_done, e->stream));
         } else {
             if ((r = flush_pending(e)) != BFHIP_OK) return r;

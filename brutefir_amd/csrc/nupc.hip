@@ -92,7 +92,8 @@ nupc_emit_kernel(T *__restrict__ acc, unsigned long long pos, int A, int n_out, 
 
 thread_local std::string n_err;
 
-int nfail(int code, const std::string &msg) { n_err = msg; (void)hipGetLastError(); return code; }   // (clears the sticky runtime error)
+// (a runtime failure's sticky error is cleared; argument / state errors make no HIP call)
+int nfail(int code, const std::string &msg) { n_err = msg; if (code == BFHIP_EHIP || code == BFHIP_ENOMEM) (void)hipGetLastError(); return code; }
 
 #define NCHK(expr)                                                                          \
     do {                                                                                    \

@@ -13,6 +13,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "libbforacle.so")
 REF_SO = os.path.join(HERE, "_ref", "libbfref.so")
+REF_DELAY_SO = os.path.join(HERE, "_ref", "libbfref_delay.so")
 
 MIX_INPUT, MIX_OUTPUT = 1, 3
 
@@ -258,6 +259,7 @@ class Engine:
         if not self.h:
             raise ValueError("invalid engine parameters")
         self.out_bytes = n_out * length * realsize
+        self.in_bytes = n_in * length * realsize      # what block() reads: checked there
         self.fmt = [[None] * n_in, [None] * n_out]
 
     def __del__(self):
@@ -268,6 +270,14 @@ class Engine:
     def set_format(self, io, ch, fmt):
         lib().bfo_engine_set_format(self.h, io, ch, C.byref(fmt))
         self.fmt[io][ch] = fmt
+        if io == 0:
+            # the C side reads byte_offset + ((L-1)*spacing + 1)*bytes of the raw buffer per channel
+            # (channels without a format: planar reals, bfo_engine_new)
+            ends = []
+            for c, f in enumerate(self.fmt[0]):
+                ends.append((c + 1) * self.L * self.rs if f is None else
+                            f.byte_offset + ((self.L - 1) * f.sample_spacing + 1) * f.bytes)
+            self.in_bytes = max(ends)
 
     def set_interleaved(self, io, name):
         n = self.n_in if io == 0 else self.n_out
@@ -275,6 +285,8 @@ class Engine:
             self.set_format(io, c, f)
         if io == 1:
             self.out_bytes = n * self.L * SAMPLE_FORMATS[name][0]
+        else:
+            self.in_bytes = n * self.L * SAMPLE_FORMATS[name][0]
 
     def set_powersave(self, analog_powersave):
         lib().bfo_engine_set_powersave(self.h, analog_powersave)
@@ -297,6 +309,8 @@ class Engine:
             self.set_format(io, c, f)
         if io == 1:
             self.out_bytes = n_phys * self.L * SAMPLE_FORMATS[name][0]
+        else:
+            self.in_bytes = n_phys * self.L * SAMPLE_FORMATS[name][0]
 
     def set_delay(self, io, ch, delay):
         lib().bfo_engine_set_delay(self.h, io, ch, delay)
@@ -353,6 +367,9 @@ class Engine:
 
     def block(self, rawin):
         rawin = np.ascontiguousarray(rawin).view(np.uint8).ravel()
+        # the C side trusts the formats: a short buffer (int32 frames handed to a FLOAT64 engine, the
+        # r02 bench segfault) must stop here, as the product binding stops it
+        assert rawin.size >= self.in_bytes, (rawin.size, self.in_bytes)
         out = np.zeros(self.out_bytes, np.uint8)
         st = lib().bfo_engine_block(self.h, _ptr(rawin), _ptr(out))
         return st, out
@@ -449,3 +466,27 @@ def ref():
         L.ref_dither_randtab_ptr.argtypes = [ci]
         _ref = L
     return _ref
+
+
+_ref_delay = None
+
+
+def ref_delay():
+    """The reference's delay.c / firwindow.c (oracle/_ref/libbfref_delay.so, a library of its own:
+    only it carries the link-time placeholder for delay.c's td_* calls) or None if not built."""
+    global _ref_delay
+    if _ref_delay is None:
+        if not os.path.exists(REF_DELAY_SO):
+            try:
+                build()
+            except Exception:
+                pass
+        if not os.path.exists(REF_DELAY_SO):
+            return None
+        L = C.CDLL(REF_DELAY_SO)
+        L.ref_delay_allocate.restype = C.c_void_p
+        L.ref_delay_allocate.argtypes = [C.c_int] * 4
+        L.ref_delay_update.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.ref_firwindow_kaiser.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int]
+        _ref_delay = L
+    return _ref_delay

@@ -15,6 +15,11 @@
  *   dither.c          Tausworthe table + randmap (separate object)
  *   emalloc.c         (separate object, needed by dither.c)
  *
+ * delay.c / firwindow.c live in a library of their own (ref_delay_harness.c ->
+ * oracle/_ref/libbfref_delay.so): delay.c references three FFTW-backed symbols
+ * that have to be closed at link time, and the library that pins the hot loop
+ * carries no such placeholder.
+ *
  * The headers are "templates": fftw_convolver.c:128-168 and :435-479 in the
  * reference instantiate them by defining the macro names below and including
  * them; this file does the same instantiation, because the macro names are
@@ -44,8 +49,6 @@
 #include "dither.h"
 #include "numunion.h"
 #include "asmprot.h"
-#include "delay.h"
-#include "firwindow.h"
 
 static int n_fft, n_fft2;
 
@@ -304,24 +307,4 @@ int
 ref_dither_randtab_ptr(int channel)
 {
     return bfconf->dither_state[channel]->randtab_ptr;
-}
-
-/* ---- integer sample delay (delay.c:78-340) and the Kaiser window (firwindow.c) ---------- */
-
-void *
-ref_delay_allocate(int fragment_size, int initdelay, int maxdelay, int sample_size)
-{
-    return delay_allocate_buffer(fragment_size, initdelay, maxdelay, sample_size);
-}
-
-void
-ref_delay_update(void *db, void *buf, int sample_size, int sample_spacing, int delay, void *target)
-{
-    delay_update((delaybuffer_t *)db, buf, sample_size, sample_spacing, delay, target);
-}
-
-void
-ref_firwindow_kaiser(void *target, int len, double offset, double beta, int realsize)
-{
-    firwindow_kaiser(target, len, offset, beta, realsize);
 }

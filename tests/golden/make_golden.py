@@ -150,7 +150,6 @@ def delay_and_window(R):
         data = tod._data(case, idx)
         out["in%d" % idx] = data
         out["out%d" % idx] = tod._ref_run(R, F, ss, init, maxd, delays, data)
-    R.ref_firwindow_kaiser.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int]
     for rs in (4, 8):
         dt = np.float32 if rs == 4 else np.float64
         for k, (ln, off) in enumerate([(63, 0.0), (63, 0.37), (63, -0.25), (64, 0.0), (31, 0.99), (31, -0.01)]):
@@ -169,7 +168,7 @@ def main():
         np.savez_compressed(os.path.join(HERE, "ref_ops_%s.npz" % tag), **ops(R, rs, 100 + rs))
         np.savez_compressed(os.path.join(HERE, "ref_conv_%s.npz" % tag), **conversions(R, rs, 200 + rs))
     if len(sys.argv) == 1:
-        delay_and_window(R)
+        delay_and_window(bo.ref_delay())
         xtc_taps()
     # dither state is process-global in the reference: one precision per process
     which = sys.argv[1] if len(sys.argv) > 1 else None

@@ -24,6 +24,10 @@ def test_every_allocation_failure_is_an_error_code(hip, args):
     assert m, tail
     walked, errors, absorbed = (int(g) for g in m.groups()[:3])
     assert float(m.group(4)) < 8.0, tail                    # half-built engines give everything back
+    # the slab-retry path was lived twenty times on its own before the baseline was taken: free
+    # memory flat from the second life on (the helper exits 4 otherwise), no re-baseline in the walk
+    mr = re.search(r"retry_n=(\d+) retry_drift_mib=(-?[\d.]+)", r.stdout)
+    assert mr and float(mr.group(2)) <= 1.0, tail
     # every armed allocation was reached; it was reported as an error, or -- the coefficient slabs,
     # which retry at half the size -- absorbed
     assert walked >= 40 and errors + absorbed == walked and absorbed <= 4, tail

@@ -562,6 +562,100 @@ def test_stream_ordered_coefficients_follow_runtime_changes(hip, cv, monkeypatch
         assert cases.rel_rms(np.frombuffer(g.tobytes(), dt), np.frombuffer(w.tobytes(), dt)) <= tol, k
 
 
+@pytest.mark.parametrize("rs", [4, 8])
+def test_stream_ordered_copy_is_not_left_stale_by_changes_in_one_gap(hip, cv, monkeypatch, rs):
+    """An in-place rewrite of a partition does not change the set's address, and the rebuild of a
+    dirty plan compares the entries of the stream-ordered copy by address: a rewrite that arrives
+    in the SAME inter-block gap as a plan-dirtying change (a scale, another filter's switch), during
+    a cross-fade block (which runs without the copy) or in the gap behind one (the plan is dirty
+    again after it) must still reach the copy.  ADVICE r2 (medium): it did not."""
+    dt = np.float32 if rs == 4 else np.float64
+    L, N, I, O = 1024, 4, 8, 8
+    tol = 1e-5 if rs == 4 else 1e-12
+    assert cv.convolver_init(None, L, rs) == 1
+    rng = np.random.default_rng(13)
+    irs = {(o, i): cases.make_ir(np.random.default_rng(150 + o * I + i), L * N, I).astype(dt) for o in range(O) for i in range(I)}
+    alt = cases.make_ir(rng, L * N, I).astype(dt)
+    shm = mmap.mmap(-1, N * 2 * L * rs)
+    base = np.frombuffer(shm, dt)
+    addr = [base[b * 2 * L:].ctypes.data for b in range(N)]
+    fid = lambda o, i: o * I + i
+
+    def build(mod, stream):
+        monkeypatch.setenv("BFHIP_COEFF_STREAM", stream)
+        monkeypatch.setenv("BFHIP_MAC_TARGET_WGS", "8")
+        e = mod.Engine(L, N, rs, I, O)
+        e.set_interleaved(0, "S24_4LE")
+        e.set_interleaved(1, "FLOAT_LE" if rs == 4 else "FLOAT64_LE")
+        cs = {}
+        for (o, i), h in irs.items():
+            if mod is hip and (o, i) == (0, 0):
+                for b in range(N):
+                    _render(cv, h[b * L:(b + 1) * L], L, rs, addr[b])
+                cs[(o, i)] = e.add_coeff_processed_blocks(addr, watch=True)
+            else:
+                cs[(o, i)] = e.add_coeff(h)
+            e.add_filter(in_ch=[i], out_ch=[o], coeff=cs[(o, i)], crossfade=(o, i) == (2, 6))
+        c_alt = e.add_coeff(alt)
+        if hasattr(e, "finalize"):
+            e.finalize()
+        return e, cs, c_alt
+
+    se, scs, salt = build(hip, "2")
+    pe, pcs, palt = build(hip, "0")
+    assert se.uses_stream_layout and not pe.uses_stream_layout
+    oe, ocs, oalt = build(bo, "0")
+
+    def rewritten(key, part):
+        """the oracle's counterpart of an in-place rewrite: the whole set with one partition replaced"""
+        blk = cases.make_ir(rng, L, I).astype(dt)
+        h = irs[key].copy()
+        h[part * L:(part + 1) * L] = blk
+        return blk, oe.add_coeff(h)
+
+    b35, o35 = rewritten((3, 5), 2)
+    b41, o41 = rewritten((4, 1), 0)
+    b57, o57 = rewritten((5, 7), 1)
+    b00, o00 = rewritten((0, 0), 3)
+    blocks = cases.raw_blocks(4, 3 * N + 2, L, I, "S24_4LE")
+    for k, blk in enumerate(blocks):
+        if k == N + 1:           # an output scale (plan dirty) and an in-place rewrite in one gap
+            for e in (se, pe, oe):
+                e.set_scale(fid(1, 2), 1, 0, 0.5)
+            se.update_coeff_block(scs[(3, 5)], 2, b35)
+            pe.update_coeff_block(pcs[(3, 5)], 2, b35)
+            oe.set_coeff(fid(3, 5), o35)
+        if k == N + 3:           # this block cross-fades (no stream-ordered copy in use); rewrite in its gap
+            for e, c in ((se, salt), (pe, palt), (oe, oalt)):
+                e.set_coeff(fid(2, 6), c)
+            se.update_coeff_block(scs[(4, 1)], 0, b41)
+            pe.update_coeff_block(pcs[(4, 1)], 0, b41)
+            oe.set_coeff(fid(4, 1), o41)
+        if k == N + 4:           # the gap behind the fade block: the plan is dirty again
+            se.update_coeff_block(scs[(5, 7)], 1, b57)
+            pe.update_coeff_block(pcs[(5, 7)], 1, b57)
+            oe.set_coeff(fid(5, 7), o57)
+        if k == 2 * N + 2:       # a watched partition rewritten by another process + a scale in one gap
+            pid = os.fork()
+            if pid == 0:
+                try:
+                    cv.convolver_runtime_coeffs2cbuf(p(np.ascontiguousarray(b00)), C.c_void_p(addr[3]))
+                finally:
+                    os._exit(0)
+            assert os.waitpid(pid, 0)[1] == 0
+            oe.set_coeff(fid(0, 0), o00)
+            for e in (se, pe, oe):
+                e.set_scale(fid(6, 3), 1, 0, -0.75)
+        s1, g = se.block(blk)
+        s2, q = pe.block(blk)
+        _, w = oe.block(blk)
+        assert s1 == 0 and s2 == 0
+        if k != N + 3:
+            assert se.uses_stream_layout, k
+        assert np.array_equal(g, q), k               # same arithmetic, different memory layout
+        assert cases.rel_rms(np.frombuffer(g.tobytes(), dt), np.frombuffer(w.tobytes(), dt)) <= tol, k
+
+
 def test_coefficient_slabs_reserve_overflow_and_error_paths(hip, monkeypatch):
     """coefficient sets live in slabs (bfhip_engine_reserve_coeffs / 64 MiB + 2 GiB pieces): a
     reservation that turns out too small spills into a further slab, a rejected set (NaN among the

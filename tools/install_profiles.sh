@@ -11,7 +11,19 @@ for w in C F; do
     [ -f $S/$f ] && cp $S/$f profiles/${PFX}_$f
   done
 done
-for f in $S/bench_*.json; do [ -s "$f" ] && cp "$f" profiles/${PFX}_$(basename $f); done
+# a bench line goes to profiles/ only if it parses and its own output check passed
+for f in $S/bench_*.json; do
+  [ -s "$f" ] || continue
+  if python3 - "$f" <<'PY'
+import json, sys
+j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+v = j.get("verify")
+sys.exit(0 if (v is None or v.get("ok") is True) and j.get("value") else 1)
+PY
+  then cp "$f" profiles/${PFX}_$(basename $f)
+  else echo "REFUSED $f: no value, or verify.ok is not true"; BAD=1
+  fi
+done
 python3 - <<'PY'
 import glob, json, os, sys
 sys.path.insert(0, os.getcwd())
@@ -24,3 +36,4 @@ for f in sorted(glob.glob("profiles/*_bench_config[CF].json")):
     print(f, "ms %.4f" % j["ms_per_step"], "frac %.3f" % j["roofline"]["frac"], "traffic_stale", j["roofline"]["traffic_stale"],
           "verify", j.get("verify", {}).get("ok"))
 PY
+[ -z "$BAD" ] || { echo "install_profiles: at least one line was refused"; exit 1; }
