@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(HERE, "libbfhip.so")
 
 IN, OUT = 0, 1
 RT_SPIN, RT_NO_GRAPH, RT_COPY_ENGINE, RT_OVERLAP = 1, 2, 4, 8      # bfhip_engine_rt_begin flags
+COEFF_WATCH, COEFF_LAZY = 1, 2                                       # bfhip_engine_add_coeff_processed_blocks flags
 ST_NONFINITE, ST_SAFETY = 1, 2
 
 
@@ -103,6 +104,12 @@ def lib():
     L.bfhip_coeff_mark_dirty.restype = None
     L.bfhip_coeff_dirty_sequence.restype = C.c_ulonglong
     L.bfhip_engine_add_filter.argtypes = [vp, ci, ip, dp, ci, ip, dp, ci, ip, dp, ci, ci, ci]
+    L.bfhip_engine_set_filter_active.argtypes = [vp, ci, ci]
+    L.bfhip_engine_stage_times.argtypes = [vp, dp]
+    L.bfhip_engine_coeff_is_resident.argtypes = [vp, ci]
+    L.bfhip_engine_set_output_active.argtypes = [vp, ci, ci]
+    L.bfhip_engine_output_is_active.argtypes = [vp, ci]
+    L.bfhip_engine_set_filter_name.argtypes = [vp, ci, ci]
     L.bfhip_engine_finalize.argtypes = [vp]
     L.bfhip_engine_set_coeff.argtypes = [vp, ci, ci]
     L.bfhip_engine_set_delayblocks.argtypes = [vp, ci, ci]
@@ -279,11 +286,12 @@ class Engine:
         cbufs = np.ascontiguousarray(cbufs, self.dt)
         return _check(lib().bfhip_engine_add_coeff_processed(self.h, _ptr(cbufs), cbufs.shape[0]))
 
-    def add_coeff_processed_blocks(self, addresses, watch=False):
+    def add_coeff_processed_blocks(self, addresses, watch=False, lazy=False):
         """addresses: host address of each block's cbuf (separate allocations, the reference's
         bfconf->coeffs_data[c][i]); watch: re-upload blocks another process marks dirty"""
         arr = (C.c_void_p * len(addresses))(*addresses)
-        return _check(lib().bfhip_engine_add_coeff_processed_blocks(self.h, arr, len(addresses), int(watch)))
+        return _check(lib().bfhip_engine_add_coeff_processed_blocks(self.h, arr, len(addresses),
+                                                                    (COEFF_WATCH if watch else 0) | (COEFF_LAZY if lazy else 0)))
 
     def refresh_coeff_processed(self, coeff, block, cbuf=None):
         _check(lib().bfhip_engine_refresh_coeff_processed(self.h, coeff, block, _ptr(cbuf)))
@@ -313,6 +321,22 @@ class Engine:
             len(out_ch), _iarr(list(out_ch)), _darr(out_scale),
             coeff, delayblocks, int(crossfade)))
 
+    # ---- a shard of the configuration (one engine per filter process of the host)
+    def set_filter_active(self, f, active):
+        _check(lib().bfhip_engine_set_filter_active(self.h, f, int(active)))
+
+    def set_output_active(self, ch, active):
+        _check(lib().bfhip_engine_set_output_active(self.h, ch, int(active)))
+
+    def output_is_active(self, ch):
+        return bool(lib().bfhip_engine_output_is_active(self.h, ch))
+
+    def coeff_is_resident(self, c):
+        return bool(lib().bfhip_engine_coeff_is_resident(self.h, c))
+
+    def set_filter_name(self, f, name):
+        _check(lib().bfhip_engine_set_filter_name(self.h, f, name))
+
     def finalize(self):
         _check(lib().bfhip_engine_finalize(self.h))
 
@@ -330,11 +354,14 @@ class Engine:
         _check(lib().bfhip_engine_set_fscale(self.h, f, idx, v))
 
     # ---- per block
-    def block(self, rawin, overflow=None):
-        """host buffers in / out; returns (status bits, raw output bytes)"""
+    def block(self, rawin, overflow=None, out=None):
+        """host buffers in / out; returns (status bits, raw output bytes).  out: write into this
+        buffer (the one the engines of several filter processes share)"""
         rawin = np.ascontiguousarray(rawin).view(np.uint8).ravel()
         assert rawin.size >= self.in_bytes, (rawin.size, self.in_bytes)
-        out = np.zeros(self.out_bytes, np.uint8)
+        if out is None:
+            out = np.zeros(self.out_bytes, np.uint8)
+        assert out.dtype == np.uint8 and out.size >= self.out_bytes and out.flags.c_contiguous
         st = _check(lib().bfhip_engine_block(self.h, _ptr(rawin), _ptr(out), overflow))
         return st, out
 
@@ -365,14 +392,16 @@ class Engine:
         assert rawin.size >= self.in_bytes, (rawin.size, self.in_bytes)
         _check(lib().bfhip_engine_rt_submit(self.h, _ptr(rawin)))
 
-    def rt_wait(self, overflow=None):
-        out = np.zeros(self.out_bytes, np.uint8)
+    def rt_wait(self, overflow=None, out=None):
+        if out is None:
+            out = np.zeros(self.out_bytes, np.uint8)
+        assert out.dtype == np.uint8 and out.size >= self.out_bytes and out.flags.c_contiguous
         st = _check(lib().bfhip_engine_rt_wait(self.h, _ptr(out), overflow))
         return st, out
 
-    def rt_block(self, rawin, overflow=None):
+    def rt_block(self, rawin, overflow=None, out=None):
         self.rt_submit(rawin)
-        return self.rt_wait(overflow)
+        return self.rt_wait(overflow, out)
 
     def rt_stats(self):
         a, b, c = C.c_ulonglong(), C.c_ulonglong(), C.c_ulonglong()
@@ -448,6 +477,14 @@ class Engine:
         ms = (C.c_double * 4)()
         _check(lib().bfhip_engine_get_timing(self.h, ms))
         return {"fft_in_ms": ms[0], "mac_ms": ms[1], "ifft_out_ms": ms[2], "launches": int(ms[3])}
+
+    STAGES = ("raw2real", "time2freq", "mixscale1", "convolve", "mixscale2", "freq2time", "real2raw", "total")
+
+    def stage_times(self):
+        """the reference's `benchmark: true` columns (bfrun.c:2035-2078): (blocks averaged, {column: ms})"""
+        ms = (C.c_double * 8)()
+        n = _check(lib().bfhip_engine_stage_times(self.h, ms))
+        return n, dict(zip(self.STAGES, ms))
 
     def algorithmic_bytes(self):
         b = (C.c_double * 2)()

@@ -94,6 +94,10 @@ struct Coeff {
     // where each block lives on the host, and the change-notice generation last uploaded
     std::vector<const void *> watch_src;
     std::vector<uint64_t> watch_gen;
+    // BFHIP_COEFF_LAZY: the host blocks are remembered (watch_src) and go to the device the first
+    // time an ACTIVE filter refers to the set -- a filter process of a multi-process host holds the
+    // sets of its own filters, not the whole configuration's (d_H == nullptr until then)
+    bool lazy = false, watched = false;
 };
 
 // Pinned staging for the small per-block tables (N:1 channel jobs, delay-line moves, sub-sample
@@ -138,9 +142,19 @@ struct Filter {
     std::vector<double> in_scale, in_fscale, out_scale;
     int coeff = -1, delayblocks = 0, crossfade = 0;
     int prevcoeff = -1;
+    // false: another engine (another filter process of the host, bfrun.c:2312-2328) runs this filter.
+    // It still takes part in the PLAN -- groups, entry order, chunk boundaries are those of the whole
+    // configuration, so every output is summed in exactly the order a single engine would use --
+    // but none of its work is launched here and its coefficients are not loaded.
+    bool active = true;
+    int name = -1;                     // the host's own number for the filter (intname); -1: its index here
 };
 
 constexpr int MAX_TIMED = 4096;
+// event pairs of a timed block: 0 K1 (input transforms), 1 K2 (MAC), 2 K3 (output pass, everything
+// of it), 3 the part of the output pass behind the inverse transforms (dither, N:1 mix, sub-sample
+// delay), 4 the per-filter level kernels in front of the MAC (N-way input mixes, cascades, cross-fades)
+constexpr int EV_PAIRS = 5, EV_PER_BLOCK = 2 * EV_PAIRS;
 
 // Host mirror of the reference's integer delay buffer (delay.c:29-45, 229-340, 346-411): same
 // state variables, same decisions; the byte moves themselves are emitted as ByteOps that a
@@ -271,6 +285,14 @@ struct bfhip_engine {
     unsigned long long watch_seq = 0;       // bfhip_coeff_dirty_sequence() at the last poll
     unsigned long long watch_lost = 0;      // bfhip_dirty_lost() at the last poll
     std::vector<Filter> filters;
+    // shard of a configuration (multi-process host): which outputs this engine converts and writes.
+    // -1 = derive at finalize (fed by an active filter, or by no filter at all), 0 / 1 = set by the host
+    std::vector<signed char> out_active_set;
+    std::vector<char> out_active;          // after finalize
+    bool sharded = false;                  // some output belongs to another engine
+    struct OwnedRun { size_t offset, len, stride; };       // bytes: per frame `len` at `offset`, frames `stride` apart
+    std::vector<OwnedRun> owned_runs;      // the raw output samples this engine owns (merged channel runs)
+    std::vector<unsigned char> h_stage;    // host staging for bfhip_engine_block of a sharded engine
     bool finalized = false, finalize_failed = false, plan_dirty = true;
     unsigned int blockcounter = 0;
     // ... which wraps by a multiple of every ring depth (N, and N + 1 when a spare slot exists)
@@ -427,7 +449,7 @@ struct bfhip_engine {
 
     // timing
     bool timing = false;
-    std::vector<hipEvent_t> ev;    // 6 per block: start/stop of K1, K2, K3 on their streams
+    std::vector<hipEvent_t> ev;    // EV_PER_BLOCK per block: start/stop of the EV_PAIRS stages on their streams
     int ev_used = 0;
     int timing_stride = 1;         // time every n-th block (the event records cost ~3 us each)
     bool timed_now = false;
@@ -665,9 +687,7 @@ void launch_ifft_out(bfhip_engine *e, const void *Zp, size_t chunk_stride, int n
                        n_chunks, first, e->d_fmt[1], e->d_over, (const unsigned char *)e->d_skip_quant,
                        raw, e->d_timeout ? (T *)e->d_timeout + (size_t)first * e->L : (T *)nullptr,
                        (const c2<T> *)e->d_tw, e->safety_limit, e->d_status);
-    *err = hipGetLastError();
-    if (*err != hipSuccess) return;
-    launch_dither<T>(e, first, count, raw, err);
+    *err = hipGetLastError();          // (the dither pass behind it: do_outputs)
 }
 
 template <typename T, int LOG2L>
@@ -827,9 +847,7 @@ void launch_ifft_out_big(bfhip_engine *e, const void *Zp, size_t chunk_stride, i
                        e->d_over, (const unsigned char *)e->d_skip_quant, raw,
                        e->d_timeout ? (T *)e->d_timeout + (size_t)first * e->L : (T *)nullptr, e->L, e->safety_limit,
                        e->d_status);
-    *err = hipGetLastError();
-    if (*err != hipSuccess) return;
-    launch_dither<T>(e, first, count, raw, err);
+    *err = hipGetLastError();          // (the dither pass behind it: do_outputs)
 }
 
 template <typename T>
@@ -900,6 +918,8 @@ int cblocks_of(const bfhip_engine *e, int coeff, int delay) {   // bfrun.c:1585-
 // chunk the same number of entries, no idle blocks in the grid.  Entries whose OG sets did not
 // change since the last build are left alone (scale changes rebuild the plan, not the data).
 const void *const STREAM_KEY_STALE = (const void *)(uintptr_t)1;     // never a set's address
+void *const PROMOTED_ELSEWHERE = (void *)(uintptr_t)1;               // promoted[] of an inactive filter: no ring here
+int coeff_make_resident(bfhip_engine *e, int ci);
 
 template <typename T>
 int build_stream_layout(bfhip_engine *e, const std::vector<MacEntry<T>> &flat, const std::vector<ChunkRange> &chunks,
@@ -1019,17 +1039,40 @@ int build_plan_t(bfhip_engine *e) {
     e->any_fading = false;
 
     auto Yptr = [&](int f) { return (c2<T> *)e->d_Y + (size_t)e->y_index[f] * L; };
+    // ring ids order the entries of a group: filters go by the host's own numbering where it gave one,
+    // so that the order does not depend on the order the filters were added in
+    long NAMES = F;
+    for (auto &f : e->filters) NAMES = std::max(NAMES, (long)f.name + 1);
+    auto fname = [&](int fi) { return (long)(e->filters[fi].name >= 0 ? e->filters[fi].name : fi); };
+
+    // lazily loaded coefficient sets: whatever an active filter refers to now has to be on the device
+    for (int fi = 0; fi < F; fi++) {
+        const Filter &f = e->filters[fi];
+        if (!f.active) continue;
+        for (int c : {f.coeff, (f.crossfade && f.prevcoeff != f.coeff) ? f.prevcoeff : -1}) {
+            if (c < 0 || c >= (int)e->coeffs.size() || e->coeffs[c].d_H != nullptr) continue;
+            const int r = coeff_make_resident(e, c);
+            if (r != BFHIP_OK) return r;
+        }
+    }
+    // which terms belong to filters another engine runs: [group][entry] bit j
+    std::vector<std::vector<unsigned int>> foreign(e->n_groups);
+    double bytes_H_plan = 0;           // the whole configuration's: what the launch geometry is chosen for
 
     for (int fi = 0; fi < F; fi++) {
         const Filter &f = e->filters[fi];
         if (f.coeff >= (int)e->coeffs.size()) return fail(BFHIP_EINVAL, "filter %d: bad coeff", fi);
         const int delay = clamp_delay(e, f.delayblocks);
         const int P = f.coeff < 0 ? 1 : cblocks_of(e, f.coeff, delay);
-        const bool owner = e->owner_index[fi] >= 0 || e->promoted[fi] != nullptr;
+        // (an inactive filter is classified like an active one -- the plan's shape must not depend
+        // on who runs what -- but owns no memory here)
+        const bool owner_kind = f.in_ch.size() != 1 || !f.in_f.empty();
+        const bool owner = f.active ? (e->owner_index[fi] >= 0 || e->promoted[fi] != nullptr)
+                                    : (owner_kind || e->promoted[fi] != nullptr);
         const bool fading = f.crossfade && f.prevcoeff != f.coeff;
         const bool needY = e->is_source[fi] || fading;
-        if (fading) e->any_fading = true;
-        if (needY && e->y_index[fi] < 0) return fail(BFHIP_ESTATE, "filter %d: no output buffer reserved", fi);
+        if (fading && f.active) e->any_fading = true;
+        if (f.active && needY && e->y_index[fi] < 0) return fail(BFHIP_ESTATE, "filter %d: no output buffer reserved", fi);
 
         // where this filter's history lives and how to index it
         const c2<T> *ring;
@@ -1037,9 +1080,11 @@ int build_plan_t(bfhip_engine *e) {
         int rdelay;
         double rscale;
         if (owner) {
-            ring = e->promoted[fi] ? (const c2<T> *)e->promoted[fi]
+            ring = !f.active ? nullptr
+                 : e->promoted[fi] ? (const c2<T> *)e->promoted[fi]
                                    : (const c2<T> *)e->d_fring + (size_t)e->owner_index[fi] * e->N * L;
-            ring_id = I + fi; rdelay = 0; rscale = 1.0;
+            ring_id = I + fname(fi); rdelay = 0; rscale = 1.0;
+            if (f.active) {
             FillJob<T> job;
             memset(&job, 0, sizeof(job));
             job.ring = (c2<T> *)ring;
@@ -1064,19 +1109,20 @@ int build_plan_t(bfhip_engine *e) {
             }
             job.evalprev = job.n_up > 0 ? (T *)e->d_evalprev + (size_t)e->sink_index[fi] * L : nullptr;
             fills[e->level[fi]].push_back(job);
+            }
         } else {
             const int ch = f.in_ch[0];
             ring = (const c2<T> *)e->d_ring + (size_t)ch * e->R * L;
             ring_id = ch; rdelay = delay;
             rscale = f.in_scale[0] * e->fmt[0][e->v2p[0][ch]].scale;                         // bfrun.c:1664
         }
-        {
+        if (f.active) {
             auto &u = ring_used[ring_id];
             u.resize(e->N, 0);
             for (int p = 0; p < P; p++) u[(p + rdelay) % e->N] = 1;
         }
 
-        if (needY) {
+        if (needY && f.active) {
             FilterJob<T> job;
             job.ring = ring; job.R = owner ? e->N : e->R; job.delay = rdelay; job.scale = (T)rscale;
             job.H = f.coeff < 0 ? nullptr : (const c2<T> *)e->coeffs[f.coeff].d_H;
@@ -1098,12 +1144,13 @@ int build_plan_t(bfhip_engine *e) {
                 fades[e->level[fi]].push_back(fj);
             }
         }
+        if (needY && f.coeff >= 0) bytes_H_plan += (double)P * (double)L * (double)sizeof(c2<T>);
 
         for (size_t oi = 0; oi < f.out_ch.size(); oi++) {
             const int o = f.out_ch[oi];
             const int g = o / OG, j = o % OG;
             const double s_out = f.out_scale[oi] / e->fmt[1][e->v2p[1][o]].scale;            // bfrun.c:1850
-            const std::pair<long, int> key = needY ? std::make_pair((long)(I + F + fi), 0)
+            const std::pair<long, int> key = needY ? std::make_pair((long)(I + NAMES + fname(fi)), 0)
                                                    : std::make_pair(ring_id, rdelay);
             auto &slots = index[g][key];
             int ei = -1;
@@ -1113,16 +1160,18 @@ int build_plan_t(bfhip_engine *e) {
             if (ei < 0) {
                 MacEntry<T> ne;
                 memset(&ne, 0, sizeof(ne));
-                ne.ring = needY ? Yptr(fi) : ring;
+                ne.ring = needY ? (f.active ? Yptr(fi) : nullptr) : ring;
                 ne.R = needY ? 1 : (owner ? e->N : e->R);
                 ne.delay = needY ? 0 : rdelay;
                 ne.live = (!needY && !owner && e->d_ps_live) ? e->d_ps_live + ring_id : nullptr;
                 for (int q = 0; q < OG; q++) ne.term[q].kind = TERM_NONE;
                 per_group[g].push_back(ne);
+                foreign[g].push_back(0u);
                 ei = (int)per_group[g].size() - 1;
                 slots.push_back(ei);
             }
             MacTerm<T> &tm = per_group[g][ei].term[j];
+            if (!f.active) foreign[g][ei] |= 1u << j;
             if (needY) {
                 tm.kind = TERM_IDENT; tm.H = nullptr; tm.P = 1; tm.scale = (T)s_out;
             } else {
@@ -1130,10 +1179,29 @@ int build_plan_t(bfhip_engine *e) {
                 tm.H = f.coeff < 0 ? nullptr : (const c2<T> *)e->coeffs[f.coeff].d_H;
                 tm.P = P;
                 tm.scale = (T)(rscale * s_out);
-                if (f.coeff >= 0) bytes_H += (double)P * (double)L * (double)sizeof(c2<T>);
+                if (f.coeff >= 0) {
+                    bytes_H_plan += (double)P * (double)L * (double)sizeof(c2<T>);
+                    if (f.active) bytes_H += (double)P * (double)L * (double)sizeof(c2<T>);
+                }
             }
             per_group[g][ei].maxP = std::max(per_group[g][ei].maxP, tm.P);
         }
+    }
+
+    // Canonical entry order inside a group: by (ring, delay), then by the order in which the same
+    // key was needed again (an output fed twice from one ring).  An output's terms are then summed
+    // in an order that depends on its own filters only -- not on which other outputs share its
+    // group, nor on the order the host listed its filters in.
+    for (int g = 0; g < e->n_groups; g++) {
+        std::vector<std::pair<std::pair<std::pair<long, int>, int>, int>> order;     // ((key, n-th use), old index)
+        for (auto &kv : index[g])
+            for (size_t n = 0; n < kv.second.size(); n++) order.push_back({{kv.first, (int)n}, kv.second[n]});
+        std::sort(order.begin(), order.end());
+        std::vector<MacEntry<T>> sorted;
+        std::vector<unsigned int> fsorted;
+        for (auto &o : order) { sorted.push_back(per_group[g][o.second]); fsorted.push_back(foreign[g][o.second]); }
+        per_group[g].swap(sorted);
+        foreign[g].swap(fsorted);
     }
 
     // launch geometry: one fat workgroup per CU measured best on MI355X (tools/tune_mac.py): each
@@ -1164,7 +1232,7 @@ int build_plan_t(bfhip_engine *e) {
         double best = 1e30;
         for (int c = 1; c <= s_full; c++) {
             const double wgs = std::min(256.0, (double)e->n_tiles * e->n_groups * c);
-            const double t_mac = std::max(std::max(13e-6, bytes_H / 6.4e12), bytes_H / (wgs * rate));
+            const double t_mac = std::max(std::max(13e-6, bytes_H_plan / 6.4e12), bytes_H_plan / (wgs * rate));
             const double t_out = 2e-6 * c;
             if (t_mac + t_out < best - 1e-9) { best = t_mac + t_out; S = c; }
         }
@@ -1172,21 +1240,25 @@ int build_plan_t(bfhip_engine *e) {
 
     // few filters with many partitions (room correction): split entries along p until every
     // group has S work items
-    for (auto &v : per_group) {
+    for (int g = 0; g < e->n_groups; g++) {
+        auto &v = per_group[g];
         if (v.empty() || (int)v.size() >= S) continue;
         const int parts = (S + (int)v.size() - 1) / (int)v.size();
         std::vector<MacEntry<T>> split;
-        for (auto &en : v) {
+        std::vector<unsigned int> fsplit;
+        for (size_t i = 0; i < v.size(); i++) {
+            const MacEntry<T> &en = v[i];
             const int len = en.maxP;
             const int np = std::max(1, std::min(parts, len));
             for (int q = 0; q < np; q++) {
                 MacEntry<T> sub = en;
                 sub.p0 = (int)((long)len * q / np);
                 sub.maxP = (int)((long)len * (q + 1) / np);
-                if (sub.maxP > sub.p0) split.push_back(sub);
+                if (sub.maxP > sub.p0) { split.push_back(sub); fsplit.push_back(foreign[g][i]); }
             }
         }
         v.swap(split);
+        foreign[g].swap(fsplit);
     }
     size_t max_entries = 1;
     for (auto &v : per_group) max_entries = std::max(max_entries, v.size());
@@ -1220,25 +1292,44 @@ int build_plan_t(bfhip_engine *e) {
         }
     }
 
+    // chunk boundaries from the WHOLE plan; then the terms of filters another engine runs are taken
+    // out (an entry's path -- crossbar, single term, generic -- stays the one the whole plan gave it:
+    // the single-term path rounds differently from the others), entries left empty are dropped
     std::vector<MacEntry<T>> flat;
     std::vector<ChunkRange> chunks((size_t)e->n_groups * S);
     for (int g = 0; g < e->n_groups; g++) {
         const auto &v = per_group[g];
         long total = 0;
         for (auto &en : v) total += en.maxP - en.p0;
-        const int base = (int)flat.size();
         size_t pos = 0;
         long acc = 0;
         for (int c = 0; c < S; c++) {
             ChunkRange cr;
-            cr.begin = base + (int)pos;
+            cr.begin = (int)flat.size();
             const long want = (total * (c + 1) + S - 1) / S;
-            while (pos < v.size() && (acc < want || c == S - 1)) { acc += v[pos].maxP - v[pos].p0; pos++; }
-            cr.end = base + (int)pos;
+            while (pos < v.size() && (acc < want || c == S - 1)) {
+                acc += v[pos].maxP - v[pos].p0;
+                MacEntry<T> en = v[pos];
+                const unsigned int fm = foreign[g][pos];
+                pos++;
+                if (fm) {
+                    unsigned int present = 0;
+                    for (int q = 0; q < OG; q++) if (en.term[q].kind != TERM_NONE) present |= 1u << q;
+                    const unsigned int keep = present & ~fm;
+                    if (keep == 0) continue;                              // nothing of ours in it
+                    if (en.dense == 1) { en.dense = 16; en.mask = (int)keep; }
+                    else if (en.dense == 16) en.mask &= (int)keep;
+                    for (int q = 0; q < OG; q++)
+                        if (fm & (1u << q)) { en.term[q].kind = TERM_NONE; en.term[q].H = nullptr; }
+                }
+                flat.push_back(en);
+            }
+            cr.end = (int)flat.size();
             chunks[(size_t)g * S + c] = cr;
         }
-        flat.insert(flat.end(), v.begin(), v.end());
     }
+    e->all_dense = !flat.empty();
+    for (auto &en : flat) if (en.dense != 1) e->all_dense = false;
     e->n_entries = (int)flat.size();
 
     // job arrays for the levelled (non fast-path) filters, one device blob
@@ -1305,7 +1396,9 @@ int build_plan_t(bfhip_engine *e) {
     double raw = 0;
     for (int io = 0; io < 2; io++)
         for (int c = 0; c < e->n_phys[io]; c++) raw += (double)L * e->fmt[io][c].bytes;
-    e->alg_bytes_mac = bytes_H + bytes_ring + C * O;
+    int O_here = 0;
+    for (int o = 0; o < O; o++) O_here += e->out_active.empty() || e->out_active[o] ? 1 : 0;
+    e->alg_bytes_mac = bytes_H + bytes_ring + C * O_here;
     e->alg_bytes_total = e->alg_bytes_mac + C * (I + e->n_owners) + raw;
     e->plan_dirty = false;
     return BFHIP_OK;
@@ -1376,7 +1469,8 @@ int check_format(const bfhip_format *f) {
 
 int record(bfhip_engine *e, int idx) {
     if (!e->timed_now) return BFHIP_OK;
-    HIPCHK(hipEventRecord(e->ev[(size_t)e->ev_used * 6 + idx], e->ls));
+    if (e->bs_arg != nullptr) return BFHIP_OK;           // a graph is being captured: replayed blocks are not timed
+    HIPCHK(hipEventRecord(e->ev[(size_t)e->ev_used * EV_PER_BLOCK + idx], e->ls));
     if (idx & 1) e->timed_mask |= 1 << (idx >> 1);
     return BFHIP_OK;
 }
@@ -1625,6 +1719,7 @@ int do_levels(bfhip_engine *e) {
     for (auto &lj : e->level_jobs) any = any || lj.n_fill || lj.n_filt || lj.n_fade;
     if (!any) return BFHIP_OK;
     hipError_t err = hipSuccess;
+    { const int rr = record(e, 8); if (rr != BFHIP_OK) return rr; }
     if (e->big) {
         size_t need = 1;
         for (auto &lj : e->level_jobs) need = std::max(need, std::max((size_t)lj.n_fill, (size_t)2 * lj.n_fade));
@@ -1634,7 +1729,7 @@ int do_levels(bfhip_engine *e) {
     if (e->big) DISPATCH_BIG(launch_levels_big, e, &err);
     else DISPATCH(launch_levels, e, &err);
     if (err != hipSuccess) return fail(BFHIP_EHIP, "level kernels: %s", hipGetErrorString(err));
-    return BFHIP_OK;
+    return record(e, 9);
 }
 
 int do_mac(bfhip_engine *e, void *Zp) {
@@ -1661,18 +1756,20 @@ int do_outputs(bfhip_engine *e, const void *Zp, size_t chunk_stride, int n_chunk
         n_chunks = 1;
     }
     if (e->big) { int rr = big_reserve(e, (size_t)count); if (rr != BFHIP_OK) return rr; }
+    // what follows the inverse transforms as launches of its own (dither chains, N:1 mix, sub-sample
+    // delay) is timed apart: the reference's real2raw column
+    const bool post = !e->dither_channels.empty() || !e->vout_groups.empty() || side_uses_subdelay(e, 1);
     if (e->big) DISPATCH_BIG(launch_ifft_out_big, e, Zp, chunk_stride, n_chunks, first, count, (uint8_t *)rawout_dev, &err);
-    else if (e->wave) {
-        DISPATCH_WAVE(launch_ifft_out_wave, e, Zp, chunk_stride, n_chunks, first, count, (uint8_t *)rawout_dev, &err)
-        if (err == hipSuccess) {
-            if (e->rs == 4) launch_dither<float>(e, first, count, (uint8_t *)rawout_dev, &err);
-            else launch_dither<double>(e, first, count, (uint8_t *)rawout_dev, &err);
-        }
-    }
+    else if (e->wave) { DISPATCH_WAVE(launch_ifft_out_wave, e, Zp, chunk_stride, n_chunks, first, count, (uint8_t *)rawout_dev, &err) }
     else DISPATCH(launch_ifft_out, e, Zp, chunk_stride, n_chunks, first, count, (uint8_t *)rawout_dev, &err);
     if (err != hipSuccess) return fail(BFHIP_EHIP, "ifft_out launch: %s", hipGetErrorString(err));
+    if (post) { const int rr = record(e, 6); if (rr != BFHIP_OK) return rr; }
+    if (e->rs == 4) launch_dither<float>(e, first, count, (uint8_t *)rawout_dev, &err);
+    else launch_dither<double>(e, first, count, (uint8_t *)rawout_dev, &err);
+    if (err != hipSuccess) return fail(BFHIP_EHIP, "dither launch: %s", hipGetErrorString(err));
     { int rv = do_subdelay(e, 1, nullptr); if (rv != BFHIP_OK) return rv; }
-    return do_vout(e, rawout_dev);
+    { int rv = do_vout(e, rawout_dev); if (rv != BFHIP_OK) return rv; }
+    return post ? record(e, 7) : BFHIP_OK;
 }
 
 void advance(bfhip_engine *e) {
@@ -1700,6 +1797,7 @@ int poll_coeff_changes(bfhip_engine *e) {
     int n = 0;
     for (size_t ci = 0; ci < e->coeffs.size(); ci++) {
         Coeff &c = e->coeffs[ci];
+        if (c.lazy && !c.watched) continue;                     // host pointers kept for the first load only
         for (size_t b = 0; b < c.watch_src.size(); b++) {
             const uint64_t gen = bfhip_dirty_generation(c.watch_src[b]);
             if (gen == c.watch_gen[b] && !all) continue;
@@ -1755,10 +1853,16 @@ int rt_enqueue_overlap(bfhip_engine *e, int p) {
     HIPCHK(hipEventRecord(rt.ev_h2d[p], rt.s_h2d));
     e->ls = e->stream;
     HIPCHK(hipStreamWaitEvent(e->stream, rt.ev_h2d[p], 0));
+    if ((r = record(e, 0)) != BFHIP_OK) return r;
     if ((r = do_inputs(e, rt.d_in[p])) != BFHIP_OK) return r;
+    if ((r = record(e, 1)) != BFHIP_OK) return r;
     if ((r = do_levels(e)) != BFHIP_OK) return r;
+    if ((r = record(e, 2)) != BFHIP_OK) return r;
     if ((r = do_mac(e, e->d_Zp)) != BFHIP_OK) return r;
+    if ((r = record(e, 3)) != BFHIP_OK) return r;
+    if ((r = record(e, 4)) != BFHIP_OK) return r;
     if ((r = do_outputs(e, e->d_Zp, (size_t)e->n_out_padded * e->L, e->n_chunks, 0, e->n_ch[1], rt.d_out[p])) != BFHIP_OK) return r;
+    if ((r = record(e, 5)) != BFHIP_OK) return r;
     RtCopy none;
     none.dst = nullptr; none.src = nullptr; none.n16 = 0; none.pad = 0;
     hipLaunchKernelGGL(rt_tail_kernel<0>, dim3(1), dim3(256), 0, e->stream, none, e->d_bs, e->N,
@@ -1789,10 +1893,18 @@ int rt_enqueue(bfhip_engine *e, int p) {
         hipLaunchKernelGGL(rt_copy_in_kernel<0>, dim3((cin.n16 + 255) / 256), dim3(256), 0, e->stream, cin);
         HIPCHK(hipGetLastError());
     }
+    // (plain launches of a timed engine -- bfhip_engine_enable_timing; `benchmark: true` hosts ask for
+    // BFHIP_RT_NO_GRAPH -- are bracketed by events like bfhip_engine_block_dev's; captured ones are not)
+    if ((r = record(e, 0)) != BFHIP_OK) return r;
     if ((r = do_inputs(e, e->d_rawin)) != BFHIP_OK) return r;
+    if ((r = record(e, 1)) != BFHIP_OK) return r;
     if ((r = do_levels(e)) != BFHIP_OK) return r;
+    if ((r = record(e, 2)) != BFHIP_OK) return r;
     if ((r = do_mac(e, e->d_Zp)) != BFHIP_OK) return r;
+    if ((r = record(e, 3)) != BFHIP_OK) return r;
+    if ((r = record(e, 4)) != BFHIP_OK) return r;
     if ((r = do_outputs(e, e->d_Zp, (size_t)e->n_out_padded * e->L, e->n_chunks, 0, e->n_ch[1], e->d_rawout)) != BFHIP_OK) return r;
+    if ((r = record(e, 5)) != BFHIP_OK) return r;
     if (nodes) HIPCHK(hipMemcpyAsync(rt.h_out[p], e->d_rawout, e->raw_bytes[1], hipMemcpyDeviceToHost, e->stream));
     hipLaunchKernelGGL(rt_tail_kernel<0>, dim3(nodes ? 1u : (cout.n16 + 255) / 256), dim3(256), 0, e->stream, cout,
                        e->d_bs, e->N, (const DevOverflow *)e->d_over, rt.h_over[p], e->n_ch[1], e->d_status,
@@ -2000,7 +2112,7 @@ void bfhip_engine_destroy(bfhip_engine *e) {
     (void)sync_all(e);
     if (e->coeff_arena) { for (auto &sl : e->slabs) if (sl.base) (void)hipFree(sl.base); }
     else { for (auto &c : e->coeffs) if (c.d_H) (void)hipFree(c.d_H); }
-    for (void *p : e->promoted) if (p) (void)hipFree(p);
+    for (void *p : e->promoted) if (p && p != PROMOTED_ELSEWHERE) (void)hipFree(p);
     for (int io = 0; io < 2; io++) for (auto &dl : e->vline[io]) if (dl.arena) (void)hipFree(dl.arena);
     if (e->d_incopy) (void)hipFree(e->d_incopy);
     { void *sp[] = {e->d_sd_bank, e->d_sd_rest[0], e->d_sd_rest[1], e->d_sdin, e->d_sdjobs[0], e->d_sdjobs[1]};
@@ -2280,14 +2392,46 @@ static int upload_processed_block(bfhip_engine *e, Coeff &c, int block, const vo
     return e->rs == 4 ? stream_refresh_block<float>(e, c.d_H, block) : stream_refresh_block<double>(e, c.d_H, block);
 }
 
-int bfhip_engine_add_coeff_processed_blocks(bfhip_engine *e, void *const cbufs[], int n_blocks, int watch) {
+namespace {
+// a lazily registered set goes to the device (the first time an active filter refers to it)
+int coeff_make_resident(bfhip_engine *e, int ci) {
+    Coeff &c = e->coeffs[ci];
+    if (c.d_H != nullptr) return BFHIP_OK;
+    if ((int)c.watch_src.size() != c.n_blocks) return fail(BFHIP_ESTATE, "coefficient set %d has no data", ci);
+    const size_t h_bytes = (size_t)c.n_blocks * e->L * e->csize();
+    if ((c.d_H = coeff_alloc(e, h_bytes)) == nullptr)
+        return fail(BFHIP_ENOMEM, "out of device memory for coefficient set");
+    for (int b = 0; b < c.n_blocks; b++) {
+        // generation first, data second: a notice that arrives in between is seen by the next poll
+        const uint64_t gen = c.watched ? bfhip_dirty_generation(c.watch_src[b]) : 0;
+        const int r = upload_processed_block(e, c, b, c.watch_src[b]);
+        if (r != BFHIP_OK) { coeff_release(e, c.d_H, h_bytes); c.d_H = nullptr; return r; }
+        if (c.watched) c.watch_gen[b] = gen;
+    }
+    return BFHIP_OK;
+}
+}  // namespace
+
+int bfhip_engine_add_coeff_processed_blocks(bfhip_engine *e, void *const cbufs[], int n_blocks, int flags) {
     if (!e || !cbufs || n_blocks < 1) return fail(BFHIP_EINVAL, "add_coeff_processed_blocks: bad argument");
     if (n_blocks > e->N) return fail(BFHIP_EINVAL, "coefficient set has %d blocks, engine has %d", n_blocks, e->N);
     for (int b = 0; b < n_blocks; b++) if (!cbufs[b]) return fail(BFHIP_EINVAL, "add_coeff_processed_blocks: block %d is NULL", b);
+    if (flags & ~(BFHIP_COEFF_WATCH | BFHIP_COEFF_LAZY)) return fail(BFHIP_EINVAL, "add_coeff_processed_blocks: unknown flag");
     { const int ro = check_owner(e); if (ro != BFHIP_OK) return ro; }
-    HIPCHK(hipSetDevice(e->device));
+    const bool watch = (flags & BFHIP_COEFF_WATCH) != 0, lazy = (flags & BFHIP_COEFF_LAZY) != 0;
     Coeff c;
     c.n_blocks = n_blocks;
+    c.lazy = lazy; c.watched = watch;
+    if (lazy) {
+        // nothing goes to the device yet: the host blocks (which the host keeps for its whole life,
+        // bfconf->coeffs_data) are loaded when a filter this engine runs first refers to the set
+        for (int b = 0; b < n_blocks; b++) { c.watch_src.push_back(cbufs[b]); c.watch_gen.push_back(0); }
+        if (watch) e->any_watched = true;
+        e->coeffs.push_back(c);
+        if (e->finalized) e->plan_dirty = true;
+        return (int)e->coeffs.size() - 1;
+    }
+    HIPCHK(hipSetDevice(e->device));
     const size_t h_bytes = (size_t)n_blocks * e->L * e->csize();
     if ((c.d_H = coeff_alloc(e, h_bytes)) == nullptr)
         return fail(BFHIP_ENOMEM, "out of device memory for coefficient set");
@@ -2306,6 +2450,11 @@ int bfhip_engine_add_coeff_processed_blocks(bfhip_engine *e, void *const cbufs[]
     return (int)e->coeffs.size() - 1;
 }
 
+int bfhip_engine_coeff_is_resident(const bfhip_engine *e, int coeff) {
+    if (!e || coeff < 0 || coeff >= (int)e->coeffs.size()) return 0;
+    return e->coeffs[coeff].d_H != nullptr ? 1 : 0;
+}
+
 int bfhip_engine_refresh_coeff_processed(bfhip_engine *e, int coeff, int block, const void *cbuf) {
     if (!e || coeff < 0 || coeff >= (int)e->coeffs.size() || block < 0 || block >= e->coeffs[coeff].n_blocks)
         return fail(BFHIP_EINVAL, "refresh_coeff_processed: bad argument");
@@ -2313,6 +2462,11 @@ int bfhip_engine_refresh_coeff_processed(bfhip_engine *e, int coeff, int block, 
     if (cbuf == nullptr) {
         if (c.watch_src.empty()) return fail(BFHIP_EINVAL, "refresh_coeff_processed: no host buffer known for this set");
         cbuf = c.watch_src[block];
+    }
+    if (c.d_H == nullptr) {
+        // registered lazily and not loaded yet: its host block is read when the set is first needed
+        if (cbuf != c.watch_src[block]) return fail(BFHIP_ESTATE, "refresh_coeff_processed: set %d is not on the device yet", coeff);
+        return BFHIP_OK;
     }
     { const int ro = check_owner(e); if (ro != BFHIP_OK) return ro; }
     HIPCHK(hipSetDevice(e->device));
@@ -2364,6 +2518,7 @@ int bfhip_engine_read_coeff_processed(bfhip_engine *e, int coeff, void *cbufs) {
     if (!e || !cbufs || coeff < 0 || coeff >= (int)e->coeffs.size()) return fail(BFHIP_EINVAL, "read_coeff_processed: bad argument");
     { const int ro = check_owner(e); if (ro != BFHIP_OK) return ro; }
     HIPCHK(hipSetDevice(e->device));
+    { const int rr = coeff_make_resident(e, coeff); if (rr != BFHIP_OK) return rr; }
     const int nb = e->coeffs[coeff].n_blocks;
     const size_t bytes = (size_t)nb * 2 * e->L * e->rs;
     if (bytes > e->taps_cap) {
@@ -2388,6 +2543,7 @@ int bfhip_engine_update_coeff_block(bfhip_engine *e, int coeff, int block, const
         return fail(BFHIP_EINVAL, "update_coeff_block: bad argument");
     { const int ro = check_owner(e); if (ro != BFHIP_OK) return ro; }
     HIPCHK(hipSetDevice(e->device));
+    { const int rr = coeff_make_resident(e, coeff); if (rr != BFHIP_OK) return rr; }
     const size_t bytes = (size_t)e->L * e->rs;
     if (bytes > e->taps_cap) {
         if (e->d_taps) { { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; } (void)hipFree(e->d_taps); e->d_taps = nullptr; }
@@ -2439,6 +2595,35 @@ int bfhip_engine_add_filter(bfhip_engine *e,
     return (int)e->filters.size() - 1;
 }
 
+int bfhip_engine_set_filter_active(bfhip_engine *e, int filter, int active) {
+    if (!e || filter < 0 || filter >= (int)e->filters.size()) return fail(BFHIP_EINVAL, "set_filter_active: bad argument");
+    if (e->finalized) return fail(BFHIP_ESTATE, "set_filter_active after finalize");
+    e->filters[filter].active = active != 0;
+    return BFHIP_OK;
+}
+
+int bfhip_engine_set_filter_name(bfhip_engine *e, int filter, int name) {
+    if (!e || filter < 0 || filter >= (int)e->filters.size() || name < 0) return fail(BFHIP_EINVAL, "set_filter_name: bad argument");
+    if (e->finalized) return fail(BFHIP_ESTATE, "set_filter_name after finalize");
+    for (size_t i = 0; i < e->filters.size(); i++)
+        if ((int)i != filter && e->filters[i].name == name) return fail(BFHIP_EINVAL, "set_filter_name: %d is taken", name);
+    e->filters[filter].name = name;
+    return BFHIP_OK;
+}
+
+int bfhip_engine_set_output_active(bfhip_engine *e, int ch, int active) {
+    if (!e || ch < 0 || ch >= e->n_ch[1]) return fail(BFHIP_EINVAL, "set_output_active: bad argument");
+    if (e->finalized) return fail(BFHIP_ESTATE, "set_output_active after finalize");
+    e->out_active_set.resize(e->n_ch[1], -1);
+    e->out_active_set[ch] = active ? 1 : 0;
+    return BFHIP_OK;
+}
+
+int bfhip_engine_output_is_active(const bfhip_engine *e, int ch) {
+    if (!e || ch < 0 || ch >= e->n_ch[1]) return 0;
+    return e->out_active.empty() ? 1 : (e->out_active[ch] ? 1 : 0);
+}
+
 static int finalize_impl(bfhip_engine *e);
 
 int bfhip_engine_finalize(bfhip_engine *e) {
@@ -2453,8 +2638,82 @@ int bfhip_engine_finalize(bfhip_engine *e) {
     return r;
 }
 
+// Which outputs does this engine convert and write?  (bfconf.c:2893-2931: every output is mixed
+// inside one filter process, connected filters stay in one process -- the same rules, checked.)
+static int resolve_shard(bfhip_engine *e) {
+    const int O = e->n_ch[1], F = (int)e->filters.size();
+    e->out_active_set.resize(O, -1);
+    std::vector<char> fed(O, 0), fed_here(O, 0), fed_else(O, 0);
+    for (int fi = 0; fi < F; fi++) {
+        const Filter &f = e->filters[fi];
+        for (int o : f.out_ch) { fed[o] = 1; (f.active ? fed_here : fed_else)[o] = 1; }
+        for (int g : f.in_f)
+            if (e->filters[g].active != f.active)
+                return fail(BFHIP_EINVAL, "filters %d and %d are connected: they must be run by the same engine", g, fi);
+    }
+    e->out_active.assign(O, 1);
+    e->sharded = false;
+    for (int o = 0; o < O; o++) {
+        if (fed_here[o] && fed_else[o]) return fail(BFHIP_EINVAL, "output %d is mixed from filters of two engines", o);
+        const bool derived = fed[o] ? fed_here[o] != 0 : true;
+        const bool act = e->out_active_set[o] < 0 ? derived : e->out_active_set[o] != 0;
+        if (!act && fed_here[o]) return fail(BFHIP_EINVAL, "output %d is fed by this engine's filters but marked inactive", o);
+        if (act && fed_else[o]) return fail(BFHIP_EINVAL, "output %d is fed by another engine's filters but marked active", o);
+        e->out_active[o] = act ? 1 : 0;
+        if (!act) e->sharded = true;
+    }
+    // virtual outputs that share a physical channel are mixed in the time domain by ONE engine
+    for (int o = 0; o < O; o++)
+        for (int q = o + 1; q < O; q++)
+            if (e->v2p[1][o] == e->v2p[1][q] && e->out_active[o] != e->out_active[q])
+                return fail(BFHIP_EINVAL, "outputs %d and %d share a physical channel: one engine must own both", o, q);
+    return BFHIP_OK;
+}
+
+// the raw output samples a sharded engine owns, as byte runs per frame (neighbouring channels of an
+// interleaved frame merge into one run)
+static void build_owned_runs(bfhip_engine *e) {
+    e->owned_runs.clear();
+    if (!e->sharded) return;
+    std::vector<bfhip_engine::OwnedRun> runs;
+    std::vector<char> seen(e->n_phys[1], 0);
+    for (int o = 0; o < e->n_ch[1]; o++) {
+        const int p = e->v2p[1][o];
+        if (!e->out_active[o] || seen[p]) continue;
+        seen[p] = 1;
+        const bfhip_format &f = e->fmt[1][p];
+        runs.push_back({(size_t)f.byte_offset, (size_t)f.bytes, (size_t)f.sample_spacing * f.bytes});
+    }
+    std::sort(runs.begin(), runs.end(), [](const bfhip_engine::OwnedRun &a, const bfhip_engine::OwnedRun &b) { return a.offset < b.offset; });
+    for (auto &r : runs) {
+        if (!e->owned_runs.empty()) {
+            auto &b = e->owned_runs.back();
+            if (b.stride == r.stride && b.offset + b.len == r.offset && b.len + r.len <= b.stride) { b.len += r.len; continue; }
+        }
+        e->owned_runs.push_back(r);
+    }
+}
+
+// dst <- src for the samples this engine owns; everything else in dst belongs to other engines
+static void copy_owned(const bfhip_engine *e, void *dst, const void *src) {
+    if (!e->sharded) { memcpy(dst, src, e->raw_bytes[1]); return; }
+    for (auto &r : e->owned_runs) {
+        unsigned char *d = (unsigned char *)dst + r.offset;
+        const unsigned char *s = (const unsigned char *)src + r.offset;
+        if (r.len == r.stride) { memcpy(d, s, r.len * (size_t)e->L); continue; }
+        for (int n = 0; n < e->L; n++, d += r.stride, s += r.stride) memcpy(d, s, r.len);
+    }
+}
+
+static void copy_owned_overflow(const bfhip_engine *e, bfhip_overflow dst[], const void *src) {
+    const DevOverflow *s = (const DevOverflow *)src;
+    for (int o = 0; o < e->n_ch[1]; o++)
+        if (!e->sharded || e->out_active[o]) memcpy(&dst[o], &s[o], sizeof(DevOverflow));
+}
+
 static int finalize_impl(bfhip_engine *e) {
     { const int ro = check_owner(e); if (ro != BFHIP_OK) return ro; }
+    { const int rsh = resolve_shard(e); if (rsh != BFHIP_OK) return rsh; }
     HIPCHK(hipSetDevice(e->device));
     const size_t L = e->L;
     const size_t prev_b = (size_t)e->n_ch[0] * L * e->rs;
@@ -2554,6 +2813,11 @@ static int finalize_impl(bfhip_engine *e) {
             shared[e->v2p[1][v]].push_back(v);
         }
         for (auto &kv : shared) e->vout_groups.push_back(kv.second);
+        // (groups of outputs another engine converts: not ours to mix -- resolve_shard made sure a
+        // group is owned as a whole)
+        e->vout_groups.erase(std::remove_if(e->vout_groups.begin(), e->vout_groups.end(),
+                                            [&](const std::vector<int> &g) { return !e->out_active[g[0]]; }),
+                             e->vout_groups.end());
         e->has_vchan = !e->vin_list.empty() || !e->vout_groups.empty() || e->sdf_length > 0;
         // enable_dither named PHYSICAL outputs (bfconf->dither_state[physch], bfrun.c:1933): from
         // here on the list holds the virtual channel behind each of them
@@ -2568,9 +2832,13 @@ static int finalize_impl(bfhip_engine *e) {
             }
             std::sort(byvirt.begin(), byvirt.end());
             e->dither_rank.clear(); e->dither_late.clear();
+            e->dither_channels.clear();
             for (size_t j = 0; j < byvirt.size(); j++) {
                 const int v = byvirt[j].first;
-                e->dither_channels[j] = v;
+                // an output another engine converts keeps its rank (= where its walk through the
+                // random table starts, dither.c) but has no slot here
+                if (!e->out_active[v]) continue;
+                e->dither_channels.push_back(v);
                 e->dither_rank.push_back(byvirt[j].second);
                 // shared outputs and outputs with a sub-sample filter are requantised by the N:1
                 // pass (bfrun.c:1938-2003): their dither runs on what that pass leaves behind
@@ -2606,12 +2874,16 @@ static int finalize_impl(bfhip_engine *e) {
         }
         // outputs K3 does not requantise itself (the dither pass or the N:1 mix does, from the time
         // samples K3 leaves in d_timeout)
-        if (!e->vout_groups.empty() || !e->dither_channels.empty()) {
+        // ... and outputs another engine converts: nobody here writes them or their overflow state
+        if (!e->vout_groups.empty() || !e->dither_channels.empty() || e->sharded) {
             std::vector<unsigned char> skip(e->n_ch[1], 0);
             for (auto &g : e->vout_groups) for (int v : g) skip[v] = 1;
             for (int c : e->dither_channels) skip[c] = 1;
+            for (int o = 0; o < e->n_ch[1]; o++) if (!e->out_active[o]) skip[o] = 1;
             HIPCHK(dev_alloc((void **)&e->d_skip_quant, skip.size()));
             HIPCHK(hipMemcpy(e->d_skip_quant, skip.data(), skip.size(), hipMemcpyHostToDevice));
+        }
+        if (!e->vout_groups.empty() || !e->dither_channels.empty()) {
             HIPCHK(dev_alloc(&e->d_timeout, (size_t)e->n_ch[1] * e->L * e->rs));
             HIPCHK(hipMemset(e->d_timeout, 0, (size_t)e->n_ch[1] * e->L * e->rs));
         }
@@ -2623,6 +2895,7 @@ static int finalize_impl(bfhip_engine *e) {
     HIPCHK(hipMemset(e->d_status, 0, sizeof(int)));
     e->raw_bytes[0] = raw_extent(e->fmt[0], e->n_phys[0], e->L);
     e->raw_bytes[1] = raw_extent(e->fmt[1], e->n_phys[1], e->L);
+    build_owned_runs(e);
     HIPCHK(dev_alloc((void **)&e->d_rawin, e->raw_bytes[0] + 16));       // +16: staged in 16-byte words
     HIPCHK(dev_alloc((void **)&e->d_rawout, e->raw_bytes[1] + 16));
     HIPCHK(hipMemset(e->d_rawout, 0, e->raw_bytes[1]));
@@ -2638,12 +2911,13 @@ static int finalize_impl(bfhip_engine *e) {
             const Filter &f = e->filters[fi];
             for (int g : f.in_f) { e->is_source[g] = 1; e->level[fi] = std::max(e->level[fi], e->level[g] + 1); }
             maxlevel = std::max(maxlevel, e->level[fi]);
+            if (!f.active) continue;               // run by another engine: no ring, no buffers here
             if (f.in_ch.size() != 1 || !f.in_f.empty()) e->owner_index[fi] = e->n_owners++;
             if (!f.in_f.empty()) e->sink_index[fi] = e->n_sinks++;
             if (f.crossfade) e->fade_index[fi] = e->n_fadeable++;
         }
         for (int fi = 0; fi < F; fi++)
-            if (e->is_source[fi] || e->filters[fi].crossfade) e->y_index[fi] = e->n_y++;
+            if (e->filters[fi].active && (e->is_source[fi] || e->filters[fi].crossfade)) e->y_index[fi] = e->n_y++;
         e->n_levels = maxlevel + 1;
         auto zalloc = [&](void **p, size_t bytes) -> int {
             if (bytes == 0) return BFHIP_OK;
@@ -2686,6 +2960,11 @@ static int finalize_impl(bfhip_engine *e) {
 static int promote_filter(bfhip_engine *e, int fi) {
     if (!e->finalized || e->owner_index[fi] >= 0 || e->promoted[fi]) return BFHIP_OK;
     const Filter &f = e->filters[fi];
+    if (!f.active) {
+        // run by another engine, which gives it its private ring there; here only the plan's shape follows
+        if (f.in_ch.size() == 1 && f.in_f.empty()) { e->promoted[fi] = PROMOTED_ELSEWHERE; e->plan_dirty = true; }
+        return BFHIP_OK;
+    }
     { const int ro = check_owner(e); if (ro != BFHIP_OK) return ro; }
     HIPCHK(hipSetDevice(e->device));
     const size_t bytes = (size_t)e->N * e->L * e->csize();
@@ -3008,6 +3287,18 @@ int bfhip_engine_block(bfhip_engine *e, const void *rawin, void *rawout, bfhip_o
     HIPCHK(hipMemcpyAsync(e->d_rawin, rawin, e->raw_bytes[0], hipMemcpyHostToDevice, sin));
     if ((r = bfhip_engine_block_dev(e, e->d_rawin, e->d_rawout)) != BFHIP_OK) return r;
     if ((r = flush_pending(e)) != BFHIP_OK) return r;          // host buffers: this block's output is due now
+    if (e->sharded) {
+        // rawout is shared with the engines of the other filter processes: only this engine's
+        // samples (and overflow entries) may land in it
+        e->h_stage.resize(e->raw_bytes[1] + (size_t)e->n_ch[1] * sizeof(DevOverflow));
+        HIPCHK(hipMemcpyAsync(e->h_stage.data(), e->d_rawout, e->raw_bytes[1], hipMemcpyDeviceToHost, sout));
+        if (overflow) HIPCHK(hipMemcpyAsync(e->h_stage.data() + e->raw_bytes[1], e->d_over, e->n_ch[1] * sizeof(DevOverflow), hipMemcpyDeviceToHost, sout));
+        const int st = bfhip_engine_sync(e);
+        if (st < 0) return st;
+        copy_owned(e, rawout, e->h_stage.data());
+        if (overflow) copy_owned_overflow(e, overflow, e->h_stage.data() + e->raw_bytes[1]);
+        return st;
+    }
     HIPCHK(hipMemcpyAsync(rawout, e->d_rawout, e->raw_bytes[1], hipMemcpyDeviceToHost, sout));
     if (overflow) HIPCHK(hipMemcpyAsync(overflow, e->d_over, e->n_ch[1] * sizeof(DevOverflow), hipMemcpyDeviceToHost, sout));
     return bfhip_engine_sync(e);
@@ -3095,6 +3386,7 @@ int bfhip_engine_rt_submit(bfhip_engine *e, const void *rawin) {
     } else {
         // first block after a plan change (also sets the kernels' LDS attributes outside any
         // capture), cross-fade blocks, per-block job tables: plain launches
+        timing_begin(e);
         if ((r = rt_enqueue(e, p)) != BFHIP_OK) return r;
         rt.primed = true;
         rt.n_direct++;
@@ -3133,8 +3425,8 @@ int bfhip_engine_rt_wait(bfhip_engine *e, void *rawout, bfhip_overflow overflow[
         HIPCHK(hipEventSynchronize(rt.done[p]));
     }
     rt.waited++;
-    if (rawout && rawout != rt.h_out[p]) memcpy(rawout, rt.h_out[p], e->raw_bytes[1]);
-    if (overflow) memcpy(overflow, rt.h_over[p], e->n_ch[1] * sizeof(DevOverflow));
+    if (rawout && rawout != rt.h_out[p]) copy_owned(e, rawout, rt.h_out[p]);      // (a sharded engine: its own samples only)
+    if (overflow) copy_owned_overflow(e, overflow, rt.h_over[p]);
     return rt.h_status[p][0];
 }
 
@@ -3274,7 +3566,7 @@ int bfhip_engine_enable_timing(bfhip_engine *e, int on) {
     { const int ro = check_owner(e); if (ro != BFHIP_OK) return ro; }
     HIPCHK(hipSetDevice(e->device));
     if (on && e->ev.empty()) {
-        e->ev.resize((size_t)MAX_TIMED * 6);
+        e->ev.resize((size_t)MAX_TIMED * EV_PER_BLOCK);
         for (auto &x : e->ev) HIPCHK(hipEventCreate(&x));
         e->ev_mask.assign(MAX_TIMED, 0);
     }
@@ -3298,7 +3590,7 @@ int bfhip_engine_get_timing(bfhip_engine *e, double ms[4]) {
         for (int k = 0; k < 3; k++) {
             if (!(e->ev_mask[i] & (1 << k))) continue;      // phase not launched through a timed entry point
             float t = 0;
-            HIPCHK(hipEventElapsedTime(&t, e->ev[(size_t)i * 6 + 2 * k], e->ev[(size_t)i * 6 + 2 * k + 1]));
+            HIPCHK(hipEventElapsedTime(&t, e->ev[(size_t)i * EV_PER_BLOCK + 2 * k], e->ev[(size_t)i * EV_PER_BLOCK + 2 * k + 1]));
             ms[k] += t;
             cnt[k]++;
         }
@@ -3307,6 +3599,37 @@ int bfhip_engine_get_timing(bfhip_engine *e, double ms[4]) {
     ms[3] = cnt[1];
     e->ev_used = 0;
     return BFHIP_OK;
+}
+
+// The reference's `benchmark: true` table (bfrun.c:2035-2078), device side.
+int bfhip_engine_stage_times(bfhip_engine *e, double ms[8]) {
+    if (!e || !ms) return fail(BFHIP_EINVAL, "stage_times: bad argument");
+    { const int ro = check_owner(e); if (ro != BFHIP_OK) return ro; }
+    HIPCHK(hipSetDevice(e->device));
+    { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
+    for (int k = 0; k < 8; k++) ms[k] = 0;
+    double sum[EV_PAIRS] = {0, 0, 0, 0, 0};
+    int n_blocks = 0;
+    for (int i = 0; i < e->ev_used; i++) {
+        if (!(e->ev_mask[i] & 2)) continue;                 // no MAC timed: not a whole block
+        n_blocks++;
+        for (int k = 0; k < EV_PAIRS; k++) {
+            if (!(e->ev_mask[i] & (1 << k))) continue;
+            float t = 0;
+            HIPCHK(hipEventElapsedTime(&t, e->ev[(size_t)i * EV_PER_BLOCK + 2 * k], e->ev[(size_t)i * EV_PER_BLOCK + 2 * k + 1]));
+            sum[k] += t;
+        }
+    }
+    e->ev_used = 0;
+    if (n_blocks == 0) return 0;
+    const double post = sum[3] / n_blocks, out = sum[2] / n_blocks;
+    ms[1] = sum[0] / n_blocks;                              // time2freq (+ raw2real, fused)
+    ms[2] = sum[4] / n_blocks;                              // mixscale1: the per-filter input mixes / cascades
+    ms[3] = sum[1] / n_blocks;                              // convolve (+ mixscale1 of plain filters, mixscale2: fused)
+    ms[5] = out > post ? out - post : 0.0;                  // freq2time (+ real2raw of undithered 1:1 outputs, fused)
+    ms[6] = post;                                           // real2raw: dither, N:1 mix, sub-sample delay passes
+    ms[7] = ms[1] + ms[2] + ms[3] + ms[5] + ms[6];
+    return n_blocks;
 }
 
 int bfhip_engine_algorithmic_bytes(bfhip_engine *e, double bytes[2]) {

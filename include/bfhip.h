@@ -159,13 +159,22 @@ int bfhip_engine_add_coeff_processed(bfhip_engine *e, const void *cbufs, int n_b
 int bfhip_engine_read_coeff_processed(bfhip_engine *e, int coeff, void *cbufs);
 /* The same for what an UNMODIFIED bfconf holds: bfconf->coeffs_data[c][0..n_blocks) are separate
    allocations (bfconf.c:1994-2009: one convolver_coeffs2cbuf() result, or one slice of a
-   shared-memory segment, per block).  watch != 0: the set may be rewritten at run time by another
+   shared-memory segment, per block).  BFHIP_COEFF_WATCH: the set may be rewritten at run time by another
    process (bflogic_eq renders into coeffs_data[c][i] in ITS process through
    bfaccess->convolver_coeffs2cbuf, rendereq.h:87-91); the engine remembers the host address of
    every block and, at the start of each block, re-uploads the ones whose change notice moved --
-   see bfhip_coeff_mark_dirty() below.  The pointers must stay valid for the engine's life. */
+   see bfhip_coeff_mark_dirty() below.  The pointers must stay valid for the engine's life.
+   flags: BFHIP_COEFF_WATCH as above; BFHIP_COEFF_LAZY: nothing goes to the device yet -- the
+   host blocks are loaded the first time a filter THIS engine runs refers to the set (an engine that
+   runs a shard of the configuration, bfhip_engine_set_filter_active, then holds the sets of its own
+   filters only; a run-time switch to a set not seen before loads it at that block). */
+#define BFHIP_COEFF_WATCH 1
+#define BFHIP_COEFF_LAZY 2
 int bfhip_engine_add_coeff_processed_blocks(bfhip_engine *e, void *const cbufs[], int n_blocks,
-                                            int watch);
+                                            int flags);
+/* 1: the set's partitions are in device memory (always, unless it was registered BFHIP_COEFF_LAZY
+   and no filter this engine runs has referred to it yet) */
+int bfhip_engine_coeff_is_resident(const bfhip_engine *e, int coeff);
 /* re-upload one partition of a loaded set from a cbuf in the reference's layout now (cbuf NULL:
    from the address given to add_coeff_processed_blocks) */
 int bfhip_engine_refresh_coeff_processed(bfhip_engine *e, int coeff, int block, const void *cbuf);
@@ -192,6 +201,31 @@ int bfhip_engine_add_filter(bfhip_engine *e,
                             int n_in_f, const int in_f[], const double in_fscale[],
                             int n_out_ch, const int out_ch[], const double out_scale[],
                             int coeff, int delayblocks, int crossfade);
+
+/* ---- one engine per filter process: a SHARD of the configuration -------------------------
+   The reference splits its filters over n_processes forked filter processes (bfconf.c:2227-2318;
+   every output is mixed inside one process, connected filters stay together, bfconf.c:2893-2931;
+   bfrun.c:2312-2328 forks them).  With this library each of those processes creates its own engine
+   (on its own GPU: device = process_index % bfhip_device_count()), describes the WHOLE
+   configuration to it -- all channels, all filters -- and marks the filters the other processes
+   run inactive.  The engine plans for the whole configuration (output groups, entry order, chunk
+   boundaries: every output is summed in exactly the order a single engine would use, so the
+   outputs are bit-identical to the one-process run), launches the work of its own filters only,
+   transforms every input itself (no exchange between the processes: the two
+   synch_filter_processes barriers of bfrun.c:1563, 1873 stay as they are), and converts and
+   writes only the outputs it owns: in the raw output buffer the processes share, and in the
+   overflow array, everything else is left untouched -- by the device entry points (the output
+   pass skips foreign channels) and by the host ones (bfhip_engine_block, bfhip_engine_rt_wait copy
+   this engine's samples only).
+   An output is owned by the engine whose active filters feed it; outputs no filter feeds are owned
+   unless bfhip_engine_set_output_active says otherwise (the host gives them to process 0).
+   Virtual outputs that share a physical channel must be owned together.  All before finalize. */
+int bfhip_engine_set_filter_active(bfhip_engine *e, int filter, int active);
+int bfhip_engine_set_output_active(bfhip_engine *e, int ch, int active);
+int bfhip_engine_output_is_active(const bfhip_engine *e, int ch);
+/* the host's own number for a filter (struct bffilter.intname): entries are ordered by it, so that
+   the summation order does not depend on the order the filters were added in */
+int bfhip_engine_set_filter_name(bfhip_engine *e, int filter, int name);
 
 /* build the device plan; no add_* after this */
 int bfhip_engine_finalize(bfhip_engine *e);
@@ -356,6 +390,25 @@ int bfhip_engine_ring_depth(const bfhip_engine *e);
    bfhip_engine_outputs_inputs_dev launch is reported in the input slot ms[0]. */
 int bfhip_engine_enable_timing(bfhip_engine *e, int on);
 int bfhip_engine_get_timing(bfhip_engine *e, double ms[4]);
+/* The same events in the columns of the reference's `benchmark: true` table (bfrun.c:2035-2078,
+   brutefir.html:1254-1261): ms[0] raw2real, [1] time2freq, [2] mixscale1, [3] convolve, [4] mixscale2,
+   [5] freq2time, [6] real2raw, [7] total -- mean device milliseconds per block over the whole blocks
+   timed since the last call (which it resets); returns how many those were (0: none, ms all zero).
+   A stage the GPU path fuses into a neighbour has no time of its own and reads 0:
+     raw2real   = 0: sample conversion happens inside the input-transform kernel  -> time2freq
+     time2freq  = the input-transform launch (K1)
+     mixscale1  = the per-filter kernels in front of the MAC: N-way input mixes, filter-to-filter
+                  cascades, cross-fades (0 for plain one-input filters: their scale is a factor in K2)
+     convolve   = the crossbar multiply-accumulate launch (K2), input and output scales included
+     mixscale2  = 0: the output mix is the accumulation itself                     -> convolve
+     freq2time  = the output launch (K3: chunk sum, inverse transform, requantiser of plain outputs)
+     real2raw   = what runs as launches of its own behind K3: HP-TPDF dither chains, the N:1
+                  time-domain mix, sub-sample delay filters (0 without them)
+     total      = the sum of the above (device time; the host's own t[7] stays wall-clock)
+   Under the deferred-output / ping-pong schedules of bfhip_engine_block_dev the fused
+   [K3 of t-1 | K1 of t] launch is counted under time2freq.  Real-time mode: only plain launches are
+   timed (begin with BFHIP_RT_NO_GRAPH); graph-replayed periods are not.  Needs enable_timing. */
+int bfhip_engine_stage_times(bfhip_engine *e, double ms[8]);
 /* algorithmic bytes of one block per SURVEY 8(d): bytes[0] total, [1] MAC kernel only
    (coefficient partitions + ring slots read + output spectra written) */
 int bfhip_engine_algorithmic_bytes(bfhip_engine *e, double bytes[2]);

@@ -47,6 +47,16 @@ def test_patch_applies_and_compiles_against_the_reference_headers(tmp_path):
     # the fused call sits between the two timestamps the survey names, once
     body = src[src.index("\ttimestamp(&t3);"):src.index("\ttimestamp(&t4);")]
     assert body.count("bfhip_period(") == 1 and "goto bfhip_period_done;" in body
+    # n_processes > 1 is no longer refused: every forked filter process drives its own engine on
+    # its own GPU, as a shard of the whole configuration
+    assert "bfconf->n_processes != 1" not in src
+    assert "process_index % n_devices" in src and "bfhip_engine_set_filter_active(" in src
+    assert "BFHIP_COEFF_LAZY" in src and "bfhip_engine_set_output_active(" in src
+    # `benchmark: true`: the GPU path adds device times into t[0..6] before the table is printed
+    # (bfrun.c:2035-2078), and the reference's I/O delay (one period per call) is the default
+    fused = body[body.index("bfhip_period("):body.index("goto bfhip_period_done;")]
+    assert "bfhip_engine_stage_times(" in fused and "t[i] +=" in fused
+    assert 'getenv("BFHIP_TWO_PERIODS")' in src and 'getenv("BFHIP_SYNC")' not in src
     # every bfhip_* function the patch calls is declared in include/bfhip.h
     import re
     called = set(re.findall(r"\b(bfhip_(?:engine|coeff)_[a-z_]+)\s*\(", src))

@@ -124,3 +124,96 @@ def test_c_host_three_processes_hot_swap(hip, tmp_path):
             oe.set_coeff(0, c1)
         _, o = oe.block(x[b * L:(b + 1) * L].reshape(L, 1))
         assert cases.rel_rms(got[b], np.frombuffer(o.tobytes(), np.float32)) <= 1e-5, b
+
+
+def _build_bfprocs():
+    exe = os.path.join(ROOT, "examples", "bfprocs")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "bfprocs.c"), "-o", exe,
+                           "-L" + os.path.join(ROOT, "brutefir_amd"), "-lbfhip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "brutefir_amd")])
+    return exe
+
+
+@pytest.mark.parametrize("outfmt", ["S24_4LE", "S16_LE", "FLOAT_LE"])
+def test_c_host_forked_filter_processes_write_what_one_process_writes(hip, tmp_path, outfmt):
+    """examples/bfprocs.c: the reference's multi-process filter topology (bfrun.c:2312-2328) from
+    plain C -- n forked filter processes, one engine each (here all on the one GPU of the box), each
+    running the filters of the outputs it owns and writing into the SHARED raw output buffer and
+    overflow array (what patches/bfrun-bfhip.diff makes filter_process() do with n_processes > 1).
+    The output file and the overflow report of 2 and 3 processes, outputs dealt out interleaved
+    (the engine's groups of eight outputs are split between the processes) or in blocks, are
+    byte-identical to the one-process run; that run is checked against the oracle."""
+    exe = _build_bfprocs()
+    L, N, I, O, nblk = 1024, 4, 3, 11, 9
+    rng = np.random.default_rng(2026)
+    gain = 20.0 if outfmt == "S16_LE" else 1.0          # S16: loud enough to clip now and then
+    irs = (np.stack([cases.make_ir(rng, L * N, I) for _ in range(O * I + 1)]) * gain).astype(np.float32)
+    irs.tofile(tmp_path / "coeffs.f32")
+    amp = 0.9 if outfmt == "S16_LE" else 0.3
+    blocks = cases.raw_blocks(7, nblk, L, I, "S24_4LE", amplitude=amp)
+    raw = np.concatenate(blocks)[:nblk * L - 300]       # a ragged last block
+    raw.tofile(tmp_path / "in.s24")
+
+    def run(n_procs, split):
+        out = tmp_path / ("out_%d_%s.raw" % (n_procs, split))
+        r = subprocess.run([exe, str(n_procs), split, str(L), str(N), str(I), str(O), outfmt,
+                            str(tmp_path / "coeffs.f32"), str(tmp_path / "in.s24"), str(out)],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "%d blocks through %d filter process" % (nblk, n_procs) in r.stderr
+        return open(out, "rb").read(), r.stdout
+
+    one, report = run(1, "blocked")
+    assert len(one) == raw.shape[0] * O * {"S24_4LE": 4, "S16_LE": 2, "FLOAT_LE": 4}[outfmt]      # as many frames out as in
+    for n_procs, split in ((2, "interleaved"), (3, "blocked"), (3, "interleaved")):
+        got, rep = run(n_procs, split)
+        assert got == one, (n_procs, split)
+        assert rep == report, (n_procs, split)
+    if outfmt == "S16_LE":
+        assert any(" 0 overflows" not in ln for ln in report.splitlines()), report     # the counters were exercised
+    # ... and the one-process output is right: the oracle on the same file
+    oe = bo.Engine(L, N, 4, I, O)
+    oe.set_interleaved(0, "S24_4LE")
+    oe.set_interleaved(1, outfmt)
+    for o in range(O):
+        for i in range(I):
+            oe.add_filter(in_ch=[i], out_ch=[o], coeff=oe.add_coeff(irs[o * I + i]), delayblocks=(o + i) % 2)
+    oe.add_filter(in_ch=[0, I - 1], in_scale=[1.0, -0.5], out_ch=[O - 1], coeff=oe.add_coeff(irs[O * I]),
+                  delayblocks=(O - 1 + 1) % 2)
+    padded = np.concatenate([raw, np.zeros((300, I), raw.dtype)])
+    want = np.concatenate([oe.block(padded[b * L:(b + 1) * L])[1] for b in range(nblk)])
+    dt = {"S24_4LE": np.int32, "S16_LE": np.int16, "FLOAT_LE": np.float32}[outfmt]
+    w = want.view(dt).reshape(-1, O)[:raw.shape[0]]
+    g = np.frombuffer(one, dt).reshape(-1, O)
+    if outfmt == "FLOAT_LE":
+        assert cases.rel_rms(g, w) <= 1e-5
+    else:
+        assert np.abs(g.astype(np.int64) - w).max() <= 1
+
+
+def test_c_host_benchmark_table_has_device_times(hip, tmp_path):
+    """`benchmark: true` of the reference prints one line per filter process and ten periods with
+    the time of every stage (bfrun.c:2035-2078).  On the GPU path those columns come from
+    bfhip_engine_stage_times(): examples/bfprocs.c prints the same table -- time2freq, convolve and
+    freq2time are device milliseconds, the stages fused away read 0, total is their sum."""
+    exe = _build_bfprocs()
+    L, N, I, O, nblk = 4096, 4, 4, 8, 30
+    rng = np.random.default_rng(5)
+    np.stack([cases.make_ir(rng, L * N, I) for _ in range(O * I + 1)]).astype(np.float32).tofile(tmp_path / "coeffs.f32")
+    np.concatenate(cases.raw_blocks(1, nblk, L, I, "S24_4LE")).tofile(tmp_path / "in.s24")
+    r = subprocess.run([exe, "2", "blocked", str(L), str(N), str(I), str(O), "S24_4LE", str(tmp_path / "coeffs.f32"),
+                        str(tmp_path / "in.s24"), str(tmp_path / "out.raw"), "benchmark"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [[c.strip() for c in ln.split("|")] for ln in r.stderr.splitlines() if ln.count("|") == 9 and "raw2real" not in ln]
+    assert len(rows) == 2 * (nblk // 10), r.stderr            # two processes, every ten periods
+    assert len({row[0] for row in rows}) == 2                 # two pids
+    for row in rows:
+        raw2real, time2freq, mix1, conv, mix2, freq2time, real2raw, total = (float(x) for x in row[1:9])
+        assert raw2real == 0 and mix2 == 0 and real2raw == 0
+        assert time2freq > 0 and conv > 0 and freq2time > 0 and mix1 >= 0
+        assert abs(total - (time2freq + mix1 + conv + freq2time)) < 2e-3
+        assert total < 5.0                                    # milliseconds, not ticks
+    # mixscale1: the ring fill of the two-input filter, in the process that owns the last output only
+    assert len({row[0] for row in rows if float(row[3]) > 0}) == 1

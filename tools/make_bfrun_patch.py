@@ -22,17 +22,31 @@ HELPERS = r'''
 /*
  * MI355X backend (libbfhip.so): the body of one filter_process() iteration -- everything
  * between timestamp(&t3) and timestamp(&t4) -- runs on the GPU through ONE call.  Pipes,
- * the icomm snapshot, block_start/coeff_final events, the output signalling and the
- * benchmark print stay as they are.  Used when this is the only filter process and no module
- * hooks the per-buffer events (input_timed .. output_timed need the host buffers; such
- * configurations keep the unfused path below, which links the same library's convolver_*
- * symbols).  BFHIP_DISABLE=1 in the environment forces the unfused path.
+ * the icomm snapshot, block_start/coeff_final events, the filter-process barriers, the output
+ * signalling and the benchmark print stay as they are.
+ *
+ * n_processes > 1: every forked filter process drives its own engine on its own GPU
+ * (device = process_index % bfhip_device_count()).  It describes the WHOLE configuration to the
+ * engine and marks the filters of the other processes inactive (bfhip.h, "one engine per filter
+ * process"): the engine transforms every input itself, runs its own filters, and writes only
+ * the outputs its filters feed into the output buffer the processes share -- no data passes
+ * between the processes, the two synch_filter_processes() calls of the unfused body are not
+ * needed, and the output is bit-identical to the n_processes = 1 run.
+ *
+ * Not used when a module hooks the per-buffer events (input_timed .. output_timed need the host
+ * buffers) or when the virtual members of a shared physical output are mixed in different
+ * processes: such configurations keep the unfused path below, which links the same library's
+ * convolver_* symbols.  BFHIP_DISABLE=1 in the environment forces the unfused path.
  */
 #include "bfhip.h"
 
 static bfhip_engine *bfhip_eng = NULL;
 static bool_t bfhip_pipelined = false;
 static int bfhip_inflight = 0;
+static int bfhip_n_all = 0;                      /* filters of the whole configuration */
+static int bfhip_index[BF_MAXFILTERS];           /* intname -> index in the engine */
+static int bfhip_local[BF_MAXFILTERS];           /* intname -> index in this process, or -1 */
+static struct bffilter *bfhip_filter[BF_MAXFILTERS];    /* intname -> its struct bffilter */
 
 static void
 bfhip_die(const char what[])
@@ -41,10 +55,29 @@ bfhip_die(const char what[])
     bf_exit(BF_EXIT_OTHER);
 }
 
+/* which process mixes (and therefore, on the GPU, converts) a virtual output; outputs no
+   filter feeds belong to process 0 */
+static int
+bfhip_output_owner(int virtch)
+{
+    int k, i;
+
+    for (k = 0; k < bfconf->n_processes; k++) {
+        for (i = 0; i < bfconf->fproc[k].n_unique_channels[OUT]; i++) {
+            if (bfconf->fproc[k].unique_channels[OUT][i] == virtch) {
+                return k;
+            }
+        }
+    }
+    return 0;
+}
+
 static bool_t
 bfhip_wanted(void)
 {
-    if (getenv("BFHIP_DISABLE") != NULL || bfconf->n_processes != 1) {
+    int physch, i;
+
+    if (getenv("BFHIP_DISABLE") != NULL) {
         return false;
     }
     if (events.n_input_timed > 0 || events.n_input_freqd > 0 ||
@@ -53,25 +86,40 @@ bfhip_wanted(void)
     {
         return false;
     }
+    /* the members of a shared physical output are mixed in the time domain by one engine
+       (every process computes this from bfconf alone: all of them decide alike) */
+    for (physch = 0; physch < bfconf->n_physical_channels[OUT]; physch++) {
+        for (i = 1; i < bfconf->n_virtperphys[OUT][physch]; i++) {
+            if (bfhip_output_owner(bfconf->phys2virt[OUT][physch][i]) !=
+                bfhip_output_owner(bfconf->phys2virt[OUT][physch][0]))
+            {
+                return false;
+            }
+        }
+    }
     return true;
 }
 
 /* Runs in the forked filter process (HIP state does not survive fork()): builds the engine
    from what bfconf_init() left in bfconf and icomm. */
 static void
-bfhip_setup(int n_filters,
-            struct bffilter filters[],
+bfhip_setup(int process_index,
             bool_t callback_io)
 {
-    int n, i, j, c, physch, n_dither, flags;
+    int n, i, k, c, idx, physch, n_dither, n_devices, flags;
     int dither_ch[BF_MAXCHANNELS];
-    int local[BF_MAXFILTERS];
+    int from[BF_MAXFILTERS];
     double scales[BF_MAXCHANNELS], fscales[BF_MAXFILTERS];
     volatile struct bffilter_control *fc;
+    struct bffilter *flt;
     struct buffer_format *bf;
     bfhip_format f;
 
-    bfhip_eng = bfhip_engine_create(0, bfconf->filter_length, bfconf->n_blocks,
+    if ((n_devices = bfhip_device_count()) < 1) {
+        bfhip_die("device_count");
+    }
+    bfhip_eng = bfhip_engine_create(process_index % n_devices,
+                                    bfconf->filter_length, bfconf->n_blocks,
                                     bfconf->realsize, bfconf->n_channels[IN],
                                     bfconf->n_channels[OUT]);
     if (bfhip_eng == NULL) {
@@ -141,8 +189,10 @@ bfhip_setup(int n_filters,
     }
     /* Coefficient sets exactly as bfconf_init() prepared them (convolver_coeffs2cbuf in the
        parent, or "processed" / shared-memory data): one cbuf per block.  Sets in shared
-       memory may be rewritten by a module process at run time (bflogic_eq): watched. */
-    {
+       memory may be rewritten by a module process at run time (bflogic_eq): watched.  One of
+       several filter processes registers them all but loads a set only when one of ITS
+       filters first refers to it (its GPU then holds its share of the coefficients). */
+    if (bfconf->n_processes == 1) {
         double total = 0;
         for (c = 0; c < bfconf->n_coeffs; c++) {
             total += (double)bfconf->coeffs[c].n_blocks * (double)convolver_cbufsize();
@@ -152,92 +202,154 @@ bfhip_setup(int n_filters,
         }
     }
     for (c = 0; c < bfconf->n_coeffs; c++) {
+        flags = bfconf->coeffs[c].is_shared ? BFHIP_COEFF_WATCH : 0;
+        if (bfconf->n_processes > 1) {
+            flags |= BFHIP_COEFF_LAZY;
+        }
         if (bfhip_engine_add_coeff_processed_blocks(bfhip_eng,
                                                     bfconf->coeffs_data[c],
                                                     bfconf->coeffs[c].n_blocks,
-                                                    bfconf->coeffs[c].is_shared) != c)
+                                                    flags) != c)
         {
             bfhip_die("add_coeff_processed_blocks");
         }
     }
-    for (n = 0; n < n_filters; n++) {
-        fc = &icomm->fctrl[filters[n].intname];
-        for (i = 0; i < filters[n].n_filters[IN]; i++) {
-            for (j = 0; j < n_filters; j++) {
-                if (filters[n].filters[IN][i] == filters[j].intname) {
-                    break;
-                }
+    /* every filter of the configuration, process by process (inside a process bfconf has put
+       connected filters in evaluation order, bfconf.c:2933-2964); the engine orders its work by
+       intname, so the listing order changes no sample */
+    for (n = 0; n < BF_MAXFILTERS; n++) {
+        bfhip_index[n] = bfhip_local[n] = -1;
+        bfhip_filter[n] = NULL;
+    }
+    bfhip_n_all = 0;
+    for (k = 0; k < bfconf->n_processes; k++) {
+        for (n = 0; n < bfconf->fproc[k].n_filters; n++) {
+            flt = &bfconf->fproc[k].filters[n];
+            fc = &icomm->fctrl[flt->intname];
+            for (i = 0; i < flt->n_filters[IN]; i++) {
+                from[i] = bfhip_index[flt->filters[IN][i]];
+                fscales[i] = fc->fscale[i];
             }
-            local[i] = j;
-            fscales[i] = fc->fscale[i];
+            for (i = 0; i < flt->n_channels[IN]; i++) {
+                scales[i] = fc->scale[IN][i];
+            }
+            /* output scales go in a second array: reuse the tail of scales[] */
+            for (i = 0; i < flt->n_channels[OUT]; i++) {
+                scales[BF_MAXCHANNELS / 2 + i] = fc->scale[OUT][i];
+            }
+            idx = bfhip_engine_add_filter(bfhip_eng,
+                                          flt->n_channels[IN],
+                                          flt->channels[IN], scales,
+                                          flt->n_filters[IN], from, fscales,
+                                          flt->n_channels[OUT],
+                                          flt->channels[OUT],
+                                          &scales[BF_MAXCHANNELS / 2],
+                                          fc->coeff, fc->delayblocks,
+                                          flt->crossfade);
+            if (idx != bfhip_n_all ||
+                bfhip_engine_set_filter_name(bfhip_eng, idx, flt->intname) < 0 ||
+                bfhip_engine_set_filter_active(bfhip_eng, idx,
+                                               k == process_index) < 0)
+            {
+                bfhip_die("add_filter");
+            }
+            bfhip_index[flt->intname] = idx;
+            bfhip_filter[flt->intname] = flt;
+            if (k == process_index) {
+                bfhip_local[flt->intname] = n;
+            }
+            bfhip_n_all++;
         }
-        for (i = 0; i < filters[n].n_channels[IN]; i++) {
-            scales[i] = fc->scale[IN][i];
-        }
-        /* output scales go in a second array: reuse the tail of scales[] */
-        for (i = 0; i < filters[n].n_channels[OUT]; i++) {
-            scales[BF_MAXCHANNELS / 2 + i] = fc->scale[OUT][i];
-        }
-        if (bfhip_engine_add_filter(bfhip_eng,
-                                    filters[n].n_channels[IN],
-                                    filters[n].channels[IN], scales,
-                                    filters[n].n_filters[IN], local, fscales,
-                                    filters[n].n_channels[OUT],
-                                    filters[n].channels[OUT],
-                                    &scales[BF_MAXCHANNELS / 2],
-                                    fc->coeff, fc->delayblocks,
-                                    filters[n].crossfade) != n)
-        {
-            bfhip_die("add_filter");
+    }
+    if (bfconf->n_processes > 1) {
+        for (n = 0; n < bfconf->n_channels[OUT]; n++) {
+            if (bfhip_engine_set_output_active(bfhip_eng, n,
+                                               bfhip_output_owner(n) ==
+                                               process_index) < 0)
+            {
+                bfhip_die("set_output_active");
+            }
         }
     }
     if (bfhip_engine_finalize(bfhip_eng) < 0) {
         bfhip_die("finalize");
     }
-    /* Callback I/O (bfio_jack) waits for every period: lowest round trip, graph replay.
-       Blocking I/O keeps two periods in flight -- upload of t+1 and download of t-1 ride the
-       copy engines beside the kernels of t -- at the cost of one period of extra I/O delay;
-       BFHIP_SYNC=1 keeps the reference's I/O delay instead. */
-    bfhip_pipelined = !callback_io && getenv("BFHIP_SYNC") == NULL;
+    /* One period per call keeps the reference's documented I/O delay (brutefir.html:839):
+       graph replay, completion watched from the CPU.  BFHIP_TWO_PERIODS=1 (blocking I/O only)
+       keeps two periods in flight instead -- upload of t+1 and download of t-1 ride the copy
+       engines beside the kernels of t -- at the cost of one period of extra I/O delay.
+       `benchmark: true` / `debug: true`: plain launches bracketed by HIP events, so that the
+       stage table of bfrun.c:2035-2078 has device times to show. */
+    bfhip_pipelined = !callback_io && getenv("BFHIP_TWO_PERIODS") != NULL;
     flags = bfhip_pipelined ? BFHIP_RT_OVERLAP : BFHIP_RT_SPIN;
+    if (bfconf->debug || bfconf->benchmark) {
+        flags |= BFHIP_RT_NO_GRAPH;
+        if (bfhip_engine_enable_timing(bfhip_eng, 1) < 0) {
+            bfhip_die("enable_timing");
+        }
+    }
     if (bfhip_engine_rt_begin(bfhip_eng, flags) < 0) {
         bfhip_die("rt_begin");
     }
-    pinfo("MI355X backend active (%s).\n",
+    pinfo("MI355X backend active: filter process %d of %d on device %d (%s).\n",
+          process_index, bfconf->n_processes, process_index % n_devices,
           bfhip_pipelined ? "two periods in flight" : "one period per call");
 }
 
-/* one period: the fctrl snapshot just taken under the mutex goes to the engine (setters are
-   no-ops when nothing changed), then the block itself */
+/* one period: the fctrl state goes to the engine (setters are no-ops when nothing changed),
+   then the block itself.  This process's own filters come from the snapshot just taken under
+   the mutex; the other processes' filters (only the SHAPE of the plan follows them) are read
+   from icomm under the mutex here. */
 static void
-bfhip_period(int n_filters,
-             struct bffilter filters[],
-             struct bffilter_control icomm_fctrl[],
+bfhip_period(struct bffilter_control icomm_fctrl[],
              uint32_t icomm_ismuted[2][BF_MAXCHANNELS/32],
              int icomm_delay[2][BF_MAXCHANNELS],
              int icomm_subdelay[2][BF_MAXCHANNELS],
              void *inbuf,
              void *outbuf)
 {
-    int n, i, coeff, st;
+    static struct bffilter_control other;
+    struct bffilter_control *fc;
+    struct bffilter *flt;
+    int n, i, idx, coeff, st;
 
-    for (n = 0; n < n_filters; n++) {
-        coeff = icomm_fctrl[n].coeff;
+    for (n = 0; n < BF_MAXFILTERS; n++) {
+        if ((idx = bfhip_index[n]) < 0) {
+            continue;
+        }
+        flt = bfhip_filter[n];
+        if (bfhip_local[n] >= 0) {
+            fc = &icomm_fctrl[bfhip_local[n]];
+        } else {
+            icomm_mutex(1);
+            other.coeff = icomm->fctrl[n].coeff;
+            other.delayblocks = icomm->fctrl[n].delayblocks;
+            for (i = 0; i < flt->n_channels[IN]; i++) {
+                other.scale[IN][i] = icomm->fctrl[n].scale[IN][i];
+            }
+            for (i = 0; i < flt->n_channels[OUT]; i++) {
+                other.scale[OUT][i] = icomm->fctrl[n].scale[OUT][i];
+            }
+            for (i = 0; i < flt->n_filters[IN]; i++) {
+                other.fscale[i] = icomm->fctrl[n].fscale[i];
+            }
+            icomm_mutex(0);
+            fc = &other;
+        }
+        coeff = fc->coeff;
         if (events.n_coeff_final == 1) {
-            events.coeff_final[0](filters[n].intname, &coeff);
+            events.coeff_final[0](n, &coeff);
         }
-        bfhip_engine_set_coeff(bfhip_eng, n, coeff);
-        bfhip_engine_set_delayblocks(bfhip_eng, n, icomm_fctrl[n].delayblocks);
-        for (i = 0; i < filters[n].n_channels[IN]; i++) {
-            bfhip_engine_set_scale(bfhip_eng, n, BFHIP_IN, i,
-                                   icomm_fctrl[n].scale[IN][i]);
+        bfhip_engine_set_coeff(bfhip_eng, idx, coeff);
+        bfhip_engine_set_delayblocks(bfhip_eng, idx, fc->delayblocks);
+        for (i = 0; i < flt->n_channels[IN]; i++) {
+            bfhip_engine_set_scale(bfhip_eng, idx, BFHIP_IN, i, fc->scale[IN][i]);
         }
-        for (i = 0; i < filters[n].n_channels[OUT]; i++) {
-            bfhip_engine_set_scale(bfhip_eng, n, BFHIP_OUT, i,
-                                   icomm_fctrl[n].scale[OUT][i]);
+        for (i = 0; i < flt->n_channels[OUT]; i++) {
+            bfhip_engine_set_scale(bfhip_eng, idx, BFHIP_OUT, i, fc->scale[OUT][i]);
         }
-        for (i = 0; i < filters[n].n_filters[IN]; i++) {
-            bfhip_engine_set_fscale(bfhip_eng, n, i, icomm_fctrl[n].fscale[i]);
+        for (i = 0; i < flt->n_filters[IN]; i++) {
+            bfhip_engine_set_fscale(bfhip_eng, idx, i, fc->fscale[i]);
         }
     }
     FOR_IN_AND_OUT {
@@ -251,10 +363,13 @@ bfhip_period(int n_filters,
             }
         }
     }
+    /* outbuf and icomm->overflow are shared by the filter processes: the engine writes the
+       samples and the overflow entries of the outputs it owns, nothing else
+       (struct bfoverflow == bfhip_overflow) */
     if (bfhip_pipelined) {
         st = bfhip_engine_rt_submit(bfhip_eng, inbuf);
         if (st >= 0 && ++bfhip_inflight == 2) {
-            /* the period submitted one call ago; struct bfoverflow == bfhip_overflow */
+            /* the period submitted one call ago */
             st = bfhip_engine_rt_wait(bfhip_eng, outbuf,
                                       (bfhip_overflow *)icomm->overflow);
             bfhip_inflight--;
@@ -281,21 +396,31 @@ bfhip_period(int n_filters,
 
 SETUP_CALL = r'''#ifdef BF_HAVE_BFHIP
     if (bfhip_wanted()) {
-        bfhip_setup(n_filters, filters, has_cb_input_devs || has_cb_output_devs);
+        bfhip_setup(process_index, has_cb_input_devs || has_cb_output_devs);
     }
 #endif
 '''
 
 BLOCK_CALL = r'''#ifdef BF_HAVE_BFHIP
         if (bfhip_eng != NULL) {
-            bfhip_period(n_filters, filters, icomm_fctrl, icomm_ismuted,
-                         icomm_delay, icomm_subdelay,
+            bfhip_period(icomm_fctrl, icomm_ismuted, icomm_delay, icomm_subdelay,
                          inbuf[curbuf], outbuf[curbuf]);
             for (n = 0; n < n_filters; n++) {
                 if (procblocks[n] < n_blocks) {
                     procblocks[n]++;
                 } else {
                     bit_clr(partial_proc, n);
+                }
+            }
+            if ((bfconf->debug || bfconf->benchmark) && (cc + 1) % 10 == 0) {
+                /* the stage table below (mean over 10 periods, in clock ticks): device times
+                   of the periods since the last print, in the reference's columns */
+                double bfhip_ms[8];
+                if (bfhip_engine_stage_times(bfhip_eng, bfhip_ms) > 0) {
+                    for (i = 0; i < 7; i++) {
+                        t[i] += (uint64_t)(bfhip_ms[i] * 10.0 *
+                                           bfconf->cpu_mhz * 1000.0);
+                    }
                 }
             }
             goto bfhip_period_done;
