@@ -2303,6 +2303,11 @@ static int add_coeff_common(bfhip_engine *e, const void *taps, bool on_device, i
     if (n_blocks > e->N) return fail(BFHIP_EINVAL, "coefficient set needs %d blocks, engine has %d", n_blocks, e->N);
     if (n_taps > n_blocks * L) n_taps = n_blocks * L;
     const void *src = taps;
+    // Device taps: whatever produced them ran on a stream this engine knows nothing about (its own
+    // stream is non-blocking: not even the legacy default stream orders with it).  Loading is not
+    // the hot path: wait for the device before reading them, and for this engine's kernel before
+    // returning -- the buffer is the caller's again when the call returns.
+    if (on_device) HIPCHK(hipDeviceSynchronize());
     if (!on_device && n_taps > 0) {
         const size_t bytes = (size_t)n_taps * e->rs;
         if (bytes > e->taps_cap) {
@@ -2325,6 +2330,7 @@ static int add_coeff_common(bfhip_engine *e, const void *taps, bool on_device, i
         DISPATCH_BIG(launch_coeff_prep_big, e, src, n_taps, scale, c.d_H, n_blocks, &err);
     } else DISPATCH(launch_coeff_prep, e, src, n_taps, scale, c.d_H, n_blocks, &err);
     if (err != hipSuccess) { coeff_release(e, c.d_H, h_bytes); return fail(BFHIP_EHIP, "coeff_prep launch: %s", hipGetErrorString(err)); }
+    if (on_device) { int _r = sync_all(e); if (_r != BFHIP_OK) { coeff_release(e, c.d_H, h_bytes); return _r; } }
     if (!on_device) {
         // host-taps path is synchronous, like convolver_coeffs2cbuf: report NaN/Inf now
         int bad = 0;

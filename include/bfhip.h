@@ -144,7 +144,10 @@ int bfhip_engine_reserve_coeffs(bfhip_engine *e, double total_bytes);
 /* load_coeff() for a time-domain coefficient set (bfconf.c:1867-2030): split into
    n_blocks partitions of L taps (n_blocks <= 0: as many as the taps need), each through
    convolver_coeffs2cbuf (fftw_convolver.c:526-573).  taps are `realsize`-wide reals in
-   host (or, _dev, device) memory.  Returns the coefficient index (>= 0). */
+   host (or, _dev, device) memory.  Returns the coefficient index (>= 0).
+   _dev: the call waits for the device before it reads taps_dev (whatever stream produced them) and
+   for its own kernel before it returns -- the buffer is the caller's again afterwards; NaN / Inf
+   among device taps is reported by bfhip_engine_finalize. */
 int bfhip_engine_add_coeff(bfhip_engine *e, const void *taps, int n_taps, double scale,
                            int n_blocks);
 int bfhip_engine_add_coeff_dev(bfhip_engine *e, const void *taps_dev, int n_taps,

@@ -210,3 +210,49 @@ def test_config_e_shape_float64_million_taps(hip):
         if b in (0, 1, Ne - 1, Ne, Ne + 1, Ne + 2):
             err = cases.rel_rms(np.frombuffer(g.tobytes(), np.float64), np.frombuffer(o.tobytes(), np.float64))
             assert err <= 1e-12, (b, err)
+
+
+def test_every_coefficient_set_of_the_headline_configuration(full_engine):
+    """All 64 outputs x all 64 inputs = all 4096 coefficient sets (8 GiB, the stream-ordered copy's
+    every (entry, tile, partition) tile included): N silent blocks empty the rings, ONE block of
+    independent noise on every input, N silent blocks; every output over those N + 1 blocks is the
+    sum over the inputs of the linear convolution of that block with the impulse response loaded
+    for the (output, input) pair -- computed in float64 with torch.fft on the device from the
+    seeds the taps were generated from (nothing from oracle/ involved).  A set that sits at the
+    wrong place contributes a different filter: every one of them is behind this number.  And the
+    check itself is checked: one interior pair's filter replaced in the EXPECTATION must show."""
+    torch = _torch()
+    dev = torch.device("cuda", 0)
+    ge, _ = full_engine
+    silence = np.zeros((L, I), np.int32)
+    noise = cases.raw_blocks(99, 1, L, I, FMT)[0]
+    for _ in range(N):
+        assert ge.block(silence)[0] == 0
+    got = []
+    for k in range(N + 1):
+        st, g = ge.block(noise if k == 0 else silence)
+        assert st == 0
+        got.append(np.frombuffer(g.tobytes(), np.float32).reshape(L, O).copy())
+    got = torch.from_numpy(np.concatenate(got)).to(dev).to(torch.float64)      # [(N+1) L][O]
+    n_y, taps = (N + 1) * L, L * N
+    n_fft = 1
+    while n_fft < L + taps:
+        n_fft *= 2
+    x = torch.from_numpy(noise.astype(np.float64) / 8388608.0).to(dev)
+    X = torch.fft.rfft(x, n=n_fft, dim=0)
+    worst = 0.0
+    for o in range(O):
+        W = torch.zeros(n_fft // 2 + 1, dtype=torch.complex128, device=dev)
+        for i in range(I):
+            W += X[:, i] * torch.fft.rfft(_ir_dev(torch, 4321 + o * I + i, dev).to(torch.float64), n=n_fft)
+        want = torch.fft.irfft(W, n=n_fft)[:n_y]
+        err = float(torch.sqrt(((got[:, o] - want) ** 2).sum() / (want ** 2).sum()))
+        worst = max(worst, err)
+        assert err <= 1e-5, (o, err)
+        if o == 37:
+            # the expectation with ONE interior pair (37, 21) taking its neighbour's filter: the bar notices
+            W2 = W + X[:, 21] * (torch.fft.rfft(_ir_dev(torch, 4321 + o * I + 22, dev).to(torch.float64), n=n_fft)
+                                 - torch.fft.rfft(_ir_dev(torch, 4321 + o * I + 21, dev).to(torch.float64), n=n_fft))
+            bad = torch.fft.irfft(W2, n=n_fft)[:n_y]
+            assert float(torch.sqrt(((got[:, o] - bad) ** 2).sum() / (bad ** 2).sum())) > 1e-2
+    assert worst > 0

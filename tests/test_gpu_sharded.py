@@ -163,7 +163,30 @@ def test_bench_two_rank_pipeline_on_one_gpu():
     assert d["roofline"]["frac"] > 0 and "exposed_collective_ms" in d
     # the line carries its own end-to-end check of the sharded outputs (mix-down included)
     v = d["verify"]
-    assert v["ok"] and v["ranks"] == 2 and v["outputs_checked"] == 8 and v["max_abs_err"] <= 1.0
+    assert v["ok"] and v["ranks"] == 2 and v["outputs_checked"] == 8 and v["max_abs_err"] <= v["bar"]
+    assert v["coefficient_sets_exercised"] == 64
+
+
+def test_bench_output_sharded_two_ranks_on_one_gpu():
+    """`--shard output`: the reference's own process rule (every output mixed inside one process,
+    bfconf.c:2893-2931) as the multi-GPU split -- rank r transforms ALL inputs itself, owns O/N
+    outputs and their filters, and there is no data-path collective at all (the rendezvous, the
+    barriers around the timed region and the max-over-ranks time are all that is exchanged)."""
+    import json
+    import subprocess
+    env = dict(os.environ, BFHIP_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shard", "output", "--steps", "8",
+                        "--warmup", "10", "--workload", "B"], capture_output=True, text=True, timeout=280, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["status_bits"] == 0
+    assert "output-sharded" in d["config"]["parallelism"] and "no data-path collective" in d["config"]["parallelism"]
+    assert [(p["inputs"], p["outputs"], p["shard"]) for p in d["per_rank"]] == [([0, 8], [0, 4], "output"), ([0, 8], [4, 8], "output")]
+    assert d["exposed_collective_ms"] is None
+    v = d["verify"]
+    assert v["ok"] and v["ranks"] == 2 and v["outputs_checked"] == 8 and v["coefficient_sets_exercised"] == 64
 
 
 def test_bench_refuses_two_ranks_on_one_device_under_the_rccl_headline():
@@ -202,7 +225,7 @@ def test_bench_step_loop_with_a_real_rccl_reduce_scatter_on_one_rank():
     assert d["backend"].startswith("rccl") and "RCCL reduce-scatter" in d["metric"]
     assert d["config"]["status_bits"] == 0 and d["value"] > 0
     assert d["exposed_collective_ms"] is not None and d["exposed_collective_ms"] >= 0
-    assert d["verify"]["ok"] and d["verify"]["max_abs_err"] <= 1.0          # outputs behind the RCCL call are right
+    assert d["verify"]["ok"] and d["verify"]["max_abs_err"] <= d["verify"]["bar"]      # outputs behind the RCCL call are right
 
 
 def test_bench_verification_notices_wrong_outputs():
@@ -220,7 +243,11 @@ def test_bench_verification_notices_wrong_outputs():
     good = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env)
     assert good.returncode == 0, good.stderr[-2000:]
     v = json.loads([ln for ln in good.stdout.splitlines() if ln.startswith("{")][0])["verify"]
-    assert v["ok"] and v["outputs_checked"] == 8 and v["probe_inputs"] == [0, 7] and 0 < v["max_abs_err"] <= 1.0
+    # noise on EVERY input, every output checked: all 64 coefficient sets of workload B are behind the
+    # result; an integer output must be the exact value rounded to the nearest count
+    assert v["ok"] and v["outputs_checked"] == 8 and v["probe_inputs"] == list(range(8))
+    assert v["coefficient_sets_exercised"] == 64 and 0.501 <= v["bar"] < 0.52 and 0.4 < v["max_abs_err"] <= v["bar"]
+    # ONE interior (output, input) pair with the wrong filter: the check has to notice
     bad = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=dict(env, BFHIP_BENCH_VERIFY_SELFTEST="1"))
     assert bad.returncode != 0 and "WRONG" in bad.stderr
     v = json.loads([ln for ln in bad.stdout.splitlines() if ln.startswith("{")][0])["verify"]

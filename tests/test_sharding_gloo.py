@@ -79,6 +79,70 @@ def test_input_sharded_crossbar_mixdown(world):
         assert worst < 1e-12, (rank, worst)
 
 
+def _worker_out(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "oracle"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    import bforacle as bo
+    import cases
+    from brutefir_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    L, N, I, O = 64, 4, 4, 8
+    _, _, fo, co = sharding.shard_crossbar(I, O, world, rank)
+    # this rank's engine: ALL inputs (it transforms them itself), its own outputs and every filter
+    # that feeds them; its samples go to its own columns of the interleaved output frame
+    e = bo.Engine(L, N, 8, I, co)
+    e.set_interleaved(0, "FLOAT64_LE")
+    fm = bo.interleaved_formats("FLOAT64_LE", O)
+    for c in range(co):
+        e.set_format(1, c, fm[fo + c])
+    e.out_bytes = O * L * 8
+    for o in range(fo, fo + co):
+        for i in range(I):
+            h = cases.make_ir(np.random.default_rng(4321 + o * I + i), L * N, I)
+            e.add_filter(in_ch=[i], out_ch=[o - fo], coeff=e.add_coeff(h))
+    full, _ = cases.crossbar(bo.Engine, L, N, 8, I, O, "FLOAT64_LE", "FLOAT64_LE")
+    exact = True
+    for blk in cases.raw_blocks(11, N + 2, L, I, "FLOAT64_LE"):
+        _, mine = e.block(blk)                        # no exchange of any kind inside the block
+        _, want = full.block(blk)
+        frame = torch.from_numpy(mine.view(np.float64).reshape(L, O).copy())
+        frames = [torch.zeros_like(frame) for _ in range(world)]
+        dist.all_gather(frames, frame)               # (the check only: "the shared output buffer")
+        whole = np.zeros((L, O))
+        for r, fr in enumerate(frames):
+            _, _, fo_r, co_r = sharding.shard_crossbar(I, O, world, r)
+            whole[:, fo_r:fo_r + co_r] = fr.numpy()[:, fo_r:fo_r + co_r]
+        exact = exact and np.array_equal(whole, want.view(np.float64).reshape(L, O))
+    dist.destroy_process_group()
+    q.put((rank, exact))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_output_sharded_crossbar_needs_no_collective_and_is_bit_exact(world):
+    """the reference's own process rule as the multi-GPU split (bench.py --shard output, the host
+    patch with n_processes > 1): every rank transforms all inputs, owns O/world outputs and the
+    filters that feed them.  Nothing is exchanged inside a block, and because every output is summed
+    by ONE rank in the order a single engine uses, the assembled frame equals the unsharded
+    engine's bit for bit (SURVEY B.5 iii observed the same on the reference's processes)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_out, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(exact for _, exact in res), res
+
+
 def test_shard_arithmetic():
     from brutefir_amd import sharding
     assert sharding.shard_crossbar(64, 64, 8, 3) == (24, 8, 24, 8)
