@@ -722,7 +722,7 @@ def main():
     def mac_roofline(tm_, alg_mac):
         mac_s = tm_["mac_ms"] * 1e-3
         ach = alg_mac / mac_s / 1e9 if mac_s > 0 else None
-        return {"bound": "hbm", "kernel": "mac_xbar_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        return {"bound": "hbm", "kernel": "mac_diag_kernel" if eng.uses_diag_mac else "mac_xbar_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS if ach else None,
                 "algorithmic_bytes_per_launch": alg_mac, "avg_launch_ms": tm_["mac_ms"],
                 "timed_launches": tm_["launches"]}

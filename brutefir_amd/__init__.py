@@ -136,6 +136,7 @@ def lib():
     L.bfhip_engine_flush.argtypes = [vp]
     L.bfhip_engine_uses_wave_fft.argtypes = [vp]
     L.bfhip_engine_uses_stream_layout.argtypes = [vp]
+    L.bfhip_engine_uses_diag_mac.argtypes = [vp]
     L.bfhip_engine_enable_timing.argtypes = [vp, ci]
     L.bfhip_engine_get_timing.argtypes = [vp, dp]
     L.bfhip_engine_algorithmic_bytes.argtypes = [vp, dp]
@@ -464,6 +465,10 @@ class Engine:
     @property
     def uses_stream_layout(self):
         return bool(lib().bfhip_engine_uses_stream_layout(self.h))
+
+    @property
+    def uses_diag_mac(self):
+        return bool(lib().bfhip_engine_uses_diag_mac(self.h))
 
     @property
     def ring_depth(self):

@@ -419,7 +419,16 @@ struct bfhip_engine {
     int n_entries = 0;
     bool mac_nt = true;            // non-temporal coefficient loads (BFHIP_MAC_NT=0 turns them off)
     int mac_unroll = 0;            // 0: rotating three-stage pipeline; 1..4: plain unroll (BFHIP_MAC_UNROLL, tools/tune_mac.py)
+    // wide interleaved sides (>= 128 channels in one uniform frame; BFHIP_WIDE_IO=0/1): the raw frames are
+    // transposed to / from a planar copy by a coalesced pass of their own (transpose_words_kernel)
+    bool wide[2] = {false, false};
+    uint8_t *d_planar[2] = {nullptr, nullptr};     // [n_phys][L] words of the side's sample size
+    unsigned char *d_phys_skip = nullptr;          // [n_phys out] 1 = another engine's channel (shards)
     bool all_dense = false;        // every MAC entry takes the crossbar path
+    // one-to-one plans (every output fed by at most one single-term entry per chunk): mac_diag_kernel,
+    // one workgroup per (chunk, output) walking whole spectra (BFHIP_MAC_DIAG=0 keeps the crossbar kernel)
+    bool mac_diag = false;
+    const int *d_diag_jobs = nullptr;      // [n_chunks * n_out_padded] entry index or -1 (lives behind d_chunks)
     double alg_bytes_total = 0, alg_bytes_mac = 0;
 
     // real-time mode (bfhip_engine_rt_*): pinned host double buffer, the block's launch
@@ -718,7 +727,35 @@ void launch_mac(bfhip_engine *e, void *Zp, hipError_t *err) {
                        (c2<T> *)Zp, e->L, e->n_out_padded, e->n_groups, e->n_chunks, n_tc,               \
                        e->blockcounter, (int)age64, (const BlockState *)e->bs_arg,                       \
                        (NTFLAG && U == 0) ? e->hstream : StreamLayout{nullptr, 0, 0, 0})
-    if (!e->mac_nt) BFHIP_LAUNCH_MAC(false, 2);
+    if (e->mac_diag) {
+        const int n_jobs = e->n_chunks * e->n_out_padded;
+        // the spectrum of a job goes to `tsplit` workgroups (consecutive runs of tiles): ~512 workgroups
+        // in all, no partial sums -- runs of 16 - 64 KiB either way (BFHIP_DIAG_TSPLIT: 1, 2, 4 ...)
+        const int all_tiles = std::max(1, e->L / (256 * (int)(16 / sizeof(c2<T>))));
+        int tsplit = 1;
+        while (tsplit < all_tiles && tsplit < 8 && n_jobs * tsplit < 512) tsplit *= 2;
+        if (const char *env = getenv("BFHIP_DIAG_TSPLIT")) {
+            tsplit = 1;
+            while (tsplit * 2 <= std::min(all_tiles, atoi(env))) tsplit *= 2;
+        }
+        const int tiles = all_tiles / tsplit;
+#define BFHIP_LAUNCH_DIAG(NTFLAG, TL)                                                                                  \
+        hipLaunchKernelGGL((mac_diag_kernel<T, NTFLAG, TL>), dim3(n_jobs * tsplit), dim3(256), 0, e->ls,               \
+                           (const MacEntry<T> *)e->d_entries, e->d_diag_jobs, (c2<T> *)Zp, e->L, e->n_out_padded,      \
+                           e->blockcounter, (int)age64, (const BlockState *)e->bs_arg, tsplit)
+#define BFHIP_DIAG_TILES(NTFLAG)                                              \
+        switch (tiles) {                                                      \
+        case 1: BFHIP_LAUNCH_DIAG(NTFLAG, 1); break;                          \
+        case 2: BFHIP_LAUNCH_DIAG(NTFLAG, 2); break;                          \
+        case 4: BFHIP_LAUNCH_DIAG(NTFLAG, 4); break;                          \
+        case 8: BFHIP_LAUNCH_DIAG(NTFLAG, 8); break;                          \
+        default: BFHIP_LAUNCH_DIAG(NTFLAG, 16); break;                        \
+        }
+        if (e->mac_nt) { BFHIP_DIAG_TILES(true) } else { BFHIP_DIAG_TILES(false) }
+#undef BFHIP_DIAG_TILES
+#undef BFHIP_LAUNCH_DIAG
+    }
+    else if (!e->mac_nt) BFHIP_LAUNCH_MAC(false, 2);
     // the pipelined variant needs ~290 VGPRs: worth it for the pure crossbar, a loss of occupancy
     // for plans that (also) run the latency-bound per-term paths
     else if (e->mac_unroll == 0 && e->all_dense) BFHIP_LAUNCH_MAC(true, 0);
@@ -1238,27 +1275,68 @@ int build_plan_t(bfhip_engine *e) {
         }
     }
 
+    // One-to-one plans (massive_config, BASELINE configs[3]): every entry a single coefficient term,
+    // every output fed by one entry.  They get mac_diag_kernel -- a workgroup per (chunk, output)
+    // that walks whole spectra -- and their parallelism from splitting the PARTITIONS of every entry
+    // into S parts (part c of every entry = chunk c), not from bin tiles.
+    bool diag_plan = !e->big && (e->L + bins_per_wg - 1) / bins_per_wg <= 16;
+    if (const char *env = getenv("BFHIP_MAC_DIAG")) diag_plan = diag_plan && atoi(env) != 0;
+    {
+        std::vector<char> fed(e->n_out_padded, 0);
+        int n_ent = 0;
+        for (int g = 0; g < e->n_groups && diag_plan; g++)
+            for (auto &en : per_group[g]) {
+                int n_terms = 0, only = -1;
+                for (int q = 0; q < OG; q++) if (en.term[q].kind != TERM_NONE) { n_terms++; only = q; }
+                if (n_terms != 1 || en.term[only].kind != TERM_COEFF || fed[g * OG + only]) { diag_plan = false; break; }
+                fed[g * OG + only] = 1;
+                n_ent++;
+            }
+        if (n_ent == 0) diag_plan = false;
+        if (diag_plan) {
+            // ~512 workgroups keep every CU busy with two; every part costs the output pass one more
+            // partial spectrum per channel
+            int maxlen = 1;
+            for (auto &v : per_group) for (auto &en : v) maxlen = std::max(maxlen, en.maxP);
+            // (workgroups come from splitting a job's SPECTRUM first -- up to 8 runs of tiles, no partial
+            // sums -- and only then from parts of the partition axis: config D 256 entries x 2 tile runs)
+            const int all_tiles = std::max(1, e->L / bins_per_wg);
+            const int per_entry = std::min(all_tiles, 8);
+            S = std::max(1, std::min(std::min(4, maxlen), (256 + n_ent * per_entry - 1) / (n_ent * per_entry)));
+            if (const char *env = getenv("BFHIP_DIAG_SPLIT")) S = std::max(1, std::min(maxlen, atoi(env)));
+        }
+    }
+
+    std::vector<std::vector<int>> part_of(e->n_groups);     // diag plans: which part an entry is (= its chunk)
     // few filters with many partitions (room correction): split entries along p until every
     // group has S work items
     for (int g = 0; g < e->n_groups; g++) {
         auto &v = per_group[g];
-        if (v.empty() || (int)v.size() >= S) continue;
-        const int parts = (S + (int)v.size() - 1) / (int)v.size();
+        if (v.empty()) continue;
+        if (!diag_plan && (int)v.size() >= S) continue;
+        if (diag_plan && S == 1) continue;
+        const int parts = diag_plan ? S : (S + (int)v.size() - 1) / (int)v.size();
         std::vector<MacEntry<T>> split;
         std::vector<unsigned int> fsplit;
-        for (size_t i = 0; i < v.size(); i++) {
+        std::vector<int> psplit;
+        auto emit = [&](size_t i, int q) {
             const MacEntry<T> &en = v[i];
             const int len = en.maxP;
             const int np = std::max(1, std::min(parts, len));
-            for (int q = 0; q < np; q++) {
-                MacEntry<T> sub = en;
-                sub.p0 = (int)((long)len * q / np);
-                sub.maxP = (int)((long)len * (q + 1) / np);
-                if (sub.maxP > sub.p0) { split.push_back(sub); fsplit.push_back(foreign[g][i]); }
-            }
+            if (q >= np) return;
+            MacEntry<T> sub = en;
+            sub.p0 = (int)((long)len * q / np);
+            sub.maxP = (int)((long)len * (q + 1) / np);
+            if (sub.maxP > sub.p0) { split.push_back(sub); fsplit.push_back(foreign[g][i]); psplit.push_back(q); }
+        };
+        if (diag_plan) {
+            for (int q = 0; q < parts; q++) for (size_t i = 0; i < v.size(); i++) emit(i, q);      // part-major: chunk c = part c
+        } else {
+            for (size_t i = 0; i < v.size(); i++) for (int q = 0; q < parts; q++) emit(i, q);
         }
         v.swap(split);
         foreign[g].swap(fsplit);
+        if (diag_plan) part_of[g].swap(psplit);
     }
     size_t max_entries = 1;
     for (auto &v : per_group) max_entries = std::max(max_entries, v.size());
@@ -1307,7 +1385,9 @@ int build_plan_t(bfhip_engine *e) {
             ChunkRange cr;
             cr.begin = (int)flat.size();
             const long want = (total * (c + 1) + S - 1) / S;
-            while (pos < v.size() && (acc < want || c == S - 1)) {
+            // (a one-to-one plan split along p: chunk c is part c of every entry, whatever their lengths)
+            const bool by_part = diag_plan && part_of[g].size() == v.size();
+            while (pos < v.size() && (by_part ? part_of[g][pos] == c : (acc < want || c == S - 1))) {
                 acc += v[pos].maxP - v[pos].p0;
                 MacEntry<T> en = v[pos];
                 const unsigned int fm = foreign[g][pos];
@@ -1330,6 +1410,25 @@ int build_plan_t(bfhip_engine *e) {
     }
     e->all_dense = !flat.empty();
     for (auto &en : flat) if (en.dense != 1) e->all_dense = false;
+    // mac_diag_kernel's job table: the one entry behind every (chunk, output), or -1.  Checked on the
+    // plan as it came out (unequal filter lengths can put two parts of one entry into one chunk):
+    // anything unexpected keeps the crossbar kernel, which takes every plan.
+    std::vector<int> diag_jobs;
+    e->mac_diag = diag_plan && !flat.empty();
+    if (e->mac_diag) {
+        diag_jobs.assign((size_t)S * e->n_out_padded, -1);
+        for (int g = 0; g < e->n_groups && e->mac_diag; g++)
+            for (int c = 0; c < S && e->mac_diag; c++) {
+                const ChunkRange cr = chunks[(size_t)g * S + c];
+                for (int idx = cr.begin; idx < cr.end; idx++) {
+                    const MacEntry<T> &en = flat[idx];
+                    if (en.dense < 2 || en.dense >= 2 + OG) { e->mac_diag = false; break; }
+                    int &slot = diag_jobs[(size_t)c * e->n_out_padded + g * OG + (en.dense - 2)];
+                    if (slot != -1) { e->mac_diag = false; break; }
+                    slot = idx;
+                }
+            }
+    }
     e->n_entries = (int)flat.size();
 
     // job arrays for the levelled (non fast-path) filters, one device blob
@@ -1359,7 +1458,8 @@ int build_plan_t(bfhip_engine *e) {
         HIPCHK(dev_alloc(&e->d_entries, eb));
         e->entries_cap = eb;
     }
-    const size_t cb = chunks.size() * sizeof(ChunkRange);
+    const size_t cb_chunks = chunks.size() * sizeof(ChunkRange);
+    const size_t cb = cb_chunks + (e->mac_diag ? diag_jobs.size() * sizeof(int) : 0);
     if (cb > e->chunks_cap) {
         if (e->d_chunks) (void)hipFree(e->d_chunks);
         HIPCHK(dev_alloc((void **)&e->d_chunks, cb));
@@ -1372,7 +1472,12 @@ int build_plan_t(bfhip_engine *e) {
     }
     { int _r = sync_all(e); if (_r != BFHIP_OK) return _r; }
     if (!flat.empty()) HIPCHK(hipMemcpy(e->d_entries, flat.data(), flat.size() * sizeof(MacEntry<T>), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(e->d_chunks, chunks.data(), cb, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_chunks, chunks.data(), cb_chunks, hipMemcpyHostToDevice));
+    e->d_diag_jobs = nullptr;
+    if (e->mac_diag) {
+        e->d_diag_jobs = (const int *)((const unsigned char *)e->d_chunks + cb_chunks);
+        HIPCHK(hipMemcpy((void *)e->d_diag_jobs, diag_jobs.data(), diag_jobs.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
     if (!blob.empty()) HIPCHK(hipMemcpy(e->d_jobs, blob.data(), blob.size(), hipMemcpyHostToDevice));
     {   // stream-ordered coefficient copy (StreamLayout) for uniform crossbar plans
         const int r = build_stream_layout<T>(e, flat, chunks, S, bytes_H);
@@ -1443,6 +1548,13 @@ int upload_formats(bfhip_engine *e) {
                 f.alt = e->d_incopy + k * (size_t)e->L * 8;
                 f.sample_spacing = 1;
                 f.byte_offset = 0;
+            }
+            if (e->wide[io]) {
+                // the transforms read / write the planar copy: channel p's L words, contiguous
+                const int ph = e->v2p[io][v];
+                f.sample_spacing = 1;
+                if (io == 0) { f.alt = e->d_planar[0] + (size_t)ph * e->L * f.bytes; f.byte_offset = 0; }
+                else f.byte_offset = (int)((size_t)ph * e->L * f.bytes);       // relative to d_planar[1], the `raw` of the output kernels
             }
             if (io == 0 && e->sd_slot[0][v] >= 0) {
                 // sub-sample filtered: K1 reads the filtered reals (the conversion from the
@@ -1701,7 +1813,35 @@ int do_vout(bfhip_engine *e, void *rawout_dev) {
     return BFHIP_OK;
 }
 
+// ---- wide interleaved sides: frames <-> planar copy (transpose_words_kernel)
+int launch_transpose(bfhip_engine *e, int io, const void *src, void *dst, int to_planar, int first, int count) {
+    const int rows = e->L, cols = e->n_phys[io], bytes = e->fmt[io][0].bytes;
+    const dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+    const unsigned char *skip = io == 1 ? e->d_phys_skip : nullptr;
+    if (bytes == 4)
+        hipLaunchKernelGGL(transpose_words_kernel<uint32_t>, grid, dim3(256), 0, e->ls, (const uint32_t *)src, (uint32_t *)dst, rows, cols, to_planar, skip, first, count);
+    else if (bytes == 2)
+        hipLaunchKernelGGL(transpose_words_kernel<uint16_t>, grid, dim3(256), 0, e->ls, (const uint16_t *)src, (uint16_t *)dst, rows, cols, to_planar, skip, first, count);
+    else
+        hipLaunchKernelGGL(transpose_words_kernel<uint64_t>, grid, dim3(256), 0, e->ls, (const uint64_t *)src, (uint64_t *)dst, rows, cols, to_planar, skip, first, count);
+    HIPCHK(hipGetLastError());
+    return BFHIP_OK;
+}
+// in front of every launch that transforms inputs
+int pre_inputs(bfhip_engine *e, const void *rawin_dev) {
+    return e->wide[0] ? launch_transpose(e, 0, rawin_dev, e->d_planar[0], 1, 0, e->n_phys[0]) : BFHIP_OK;
+}
+// what the output kernels get as `raw`, and the pass behind them (virtual channels [first, first+count))
+uint8_t *k3_target(bfhip_engine *e, void *rawout_dev) { return e->wide[1] ? e->d_planar[1] : (uint8_t *)rawout_dev; }
+int post_outputs(bfhip_engine *e, void *rawout_dev, int first, int count) {
+    if (!e->wide[1]) return BFHIP_OK;
+    int p0 = e->n_phys[1], p1 = -1;
+    for (int v = first; v < first + count; v++) { p0 = std::min(p0, e->v2p[1][v]); p1 = std::max(p1, e->v2p[1][v]); }
+    return p1 < p0 ? BFHIP_OK : launch_transpose(e, 1, e->d_planar[1], rawout_dev, 0, p0, p1 - p0 + 1);
+}
+
 int do_inputs(bfhip_engine *e, const void *rawin_dev) {
+    { int rv = pre_inputs(e, rawin_dev); if (rv != BFHIP_OK) return rv; }
     { int rv = do_vin(e, rawin_dev); if (rv != BFHIP_OK) return rv; }
     { int rv = do_subdelay(e, 0, rawin_dev); if (rv != BFHIP_OK) return rv; }
     hipError_t err = hipSuccess;
@@ -1755,6 +1895,8 @@ int do_outputs(bfhip_engine *e, const void *Zp, size_t chunk_stride, int n_chunk
         if (err != hipSuccess) return fail(BFHIP_EHIP, "sum_partials launch: %s", hipGetErrorString(err));
         n_chunks = 1;
     }
+    void *const user_out = rawout_dev;
+    rawout_dev = k3_target(e, rawout_dev);
     if (e->big) { int rr = big_reserve(e, (size_t)count); if (rr != BFHIP_OK) return rr; }
     // what follows the inverse transforms as launches of its own (dither chains, N:1 mix, sub-sample
     // delay) is timed apart: the reference's real2raw column
@@ -1769,6 +1911,7 @@ int do_outputs(bfhip_engine *e, const void *Zp, size_t chunk_stride, int n_chunk
     if (err != hipSuccess) return fail(BFHIP_EHIP, "dither launch: %s", hipGetErrorString(err));
     { int rv = do_subdelay(e, 1, nullptr); if (rv != BFHIP_OK) return rv; }
     { int rv = do_vout(e, rawout_dev); if (rv != BFHIP_OK) return rv; }
+    { int rv = post_outputs(e, user_out, first, count); if (rv != BFHIP_OK) return rv; }
     return post ? record(e, 7) : BFHIP_OK;
 }
 
@@ -2137,7 +2280,8 @@ void bfhip_engine_destroy(bfhip_engine *e) {
                     e->d_fring, e->d_Y, e->d_Yold, e->d_evalprev, e->d_jobs,
                     e->d_dither_ch, e->d_dither_state, e->d_dither_table, e->d_randmap, e->d_skip_quant, e->d_timeout,
                     e->d_big[0], e->d_big[1], e->d_big[2], e->d_tw13, e->d_tww,
-                    e->d_ps_flags, e->d_ps_live, e->d_ps_scale, e->d_ps_acc, e->d_stream, e->d_where};
+                    e->d_ps_flags, e->d_ps_live, e->d_ps_scale, e->d_ps_acc, e->d_stream, e->d_where,
+                    e->d_planar[0], e->d_planar[1], e->d_phys_skip};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto ev : e->ev) (void)hipEventDestroy(ev);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -2894,6 +3038,34 @@ static int finalize_impl(bfhip_engine *e) {
             HIPCHK(hipMemset(e->d_timeout, 0, (size_t)e->n_ch[1] * e->L * e->rs));
         }
     }
+    // wide interleaved sides: one uniform frame of >= 128 channels (words of 2, 4 or 8 bytes, channel p
+    // at byte p * bytes of the frame), nothing on that side that reads its samples from a private
+    // copy already (N:1 inputs, sub-sample delayed inputs); BFHIP_WIDE_IO=1 takes every eligible
+    // side, 0 none
+    for (int io = 0; io < 2; io++) {
+        const int n = e->n_phys[io];
+        bool ok = n >= 1 && !e->big;
+        for (int p = 0; p < n && ok; p++) {
+            const bfhip_format &f = e->fmt[io][p];
+            ok = (f.bytes == 2 || f.bytes == 4 || f.bytes == 8) && f.bytes == e->fmt[io][0].bytes &&
+                 f.sample_spacing == n && f.byte_offset == p * f.bytes;
+        }
+        if (io == 0) ok = ok && e->vin_list.empty() && !side_uses_subdelay(e, 0);
+        int want = 0;          // (measured on config D, 256 + 256 channels: no gain, DESIGN 6 -- kept as an option)
+        if (const char *env = getenv("BFHIP_WIDE_IO")) want = atoi(env) != 0;
+        e->wide[io] = ok && want;
+        if (e->wide[io]) {
+            const size_t bytes = (size_t)n * e->L * e->fmt[io][0].bytes;
+            HIPCHK(dev_alloc((void **)&e->d_planar[io], bytes));
+            HIPCHK(hipMemset(e->d_planar[io], 0, bytes));
+        }
+    }
+    if (e->wide[1] && e->sharded) {
+        std::vector<unsigned char> skip(e->n_phys[1], 0);
+        for (int v = 0; v < e->n_ch[1]; v++) if (!e->out_active[v]) skip[e->v2p[1][v]] = 1;
+        HIPCHK(dev_alloc((void **)&e->d_phys_skip, skip.size()));
+        HIPCHK(hipMemcpy(e->d_phys_skip, skip.data(), skip.size(), hipMemcpyHostToDevice));
+    }
     int r = upload_formats(e);
     if (r != BFHIP_OK) return r;
     HIPCHK(dev_alloc((void **)&e->d_over, e->n_ch[1] * sizeof(DevOverflow)));
@@ -3100,9 +3272,11 @@ int bfhip_engine_outputs_inputs_dev(bfhip_engine *e, const void *z_dev, int firs
     if ((r = record(e, 0)) != BFHIP_OK) return r;      // the fused launch is timed in the input slot
     hipError_t err = hipSuccess;
     const int slot = (int)(e->blockcounter % (unsigned int)e->R);
-    if (e->wave) { DISPATCH_WAVE(launch_io_wave, e, z_dev, (size_t)0, 1, first, count, (uint8_t *)rawout_dev, (const uint8_t *)rawin_dev, slot, &err) }
-    else DISPATCH(launch_io, e, z_dev, first, count, (uint8_t *)rawout_dev, (const uint8_t *)rawin_dev, slot, &err);
+    if ((r = pre_inputs(e, rawin_dev)) != BFHIP_OK) return r;
+    if (e->wave) { DISPATCH_WAVE(launch_io_wave, e, z_dev, (size_t)0, 1, first, count, k3_target(e, rawout_dev), (const uint8_t *)rawin_dev, slot, &err) }
+    else DISPATCH(launch_io, e, z_dev, first, count, k3_target(e, rawout_dev), (const uint8_t *)rawin_dev, slot, &err);
     if (err != hipSuccess) return fail(BFHIP_EHIP, "io launch: %s", hipGetErrorString(err));
+    if ((r = post_outputs(e, rawout_dev, first, count)) != BFHIP_OK) return r;
     return record(e, 1);
 }
 
@@ -3150,10 +3324,12 @@ static int block_dev_impl(bfhip_engine *e, const void *rawin_dev, void *rawout_d
             if (p.n_chunks <= 2) {
                 hipError_t err = hipSuccess;
                 const int slot = (int)(e->blockcounter % (unsigned int)e->R);
+                if ((r = pre_inputs(e, rawin_dev)) != BFHIP_OK) return r;
                 DISPATCH_WAVE(launch_io_wave, e, p.Zp, p.chunk_stride, p.n_chunks, 0, e->n_ch[1],
-                              (uint8_t *)p.rawout, (const uint8_t *)rawin_dev, slot, &err)
+                              k3_target(e, p.rawout), (const uint8_t *)rawin_dev, slot, &err)
                 if (err != hipSuccess) return fail(BFHIP_EHIP, "io launch: %s", hipGetErrorString(err));
                 e->pendq.pop_front();
+                if ((r = post_outputs(e, p.rawout, 0, e->n_ch[1])) != BFHIP_OK) return r;
             } else {
                 if ((r = do_outputs(e, p.Zp, p.chunk_stride, p.n_chunks, 0, e->n_ch[1], p.rawout)) != BFHIP_OK) return r;
                 e->pendq.pop_front();
@@ -3198,10 +3374,12 @@ static int block_dev_impl(bfhip_engine *e, const void *rawin_dev, void *rawout_d
             const bfhip_engine::Pending p = e->pendq.front();     // popped once its launch is in the stream
             hipError_t err = hipSuccess;
             const int slot = (int)(e->blockcounter % (unsigned int)e->R);
+            if ((r = pre_inputs(e, rawin_dev)) != BFHIP_OK) return r;
             DISPATCH_WAVE(launch_io_wave, e, p.Zp, p.chunk_stride, p.n_chunks, 0, e->n_ch[1],
-                          (uint8_t *)p.rawout, (const uint8_t *)rawin_dev, slot, &err)
+                          k3_target(e, p.rawout), (const uint8_t *)rawin_dev, slot, &err)
             if (err != hipSuccess) return fail(BFHIP_EHIP, "io launch: %s", hipGetErrorString(err));
             e->pendq.pop_front();
+            if ((r = post_outputs(e, p.rawout, 0, e->n_ch[1])) != BFHIP_OK) return r;
             if (p.out_done) HIPCHK(hipEventRecord(p.out_done, e->stream));
         } else {
             if ((r = flush_pending(e)) != BFHIP_OK) return r;
@@ -3214,6 +3392,15 @@ static int block_dev_impl(bfhip_engine *e, const void *rawin_dev, void *rawout_d
         if ((r = record(e, 3)) != BFHIP_OK) return r;
         bfhip_engine::Pending np;
         np.Zp = Zp; np.chunk_stride = (size_t)e->n_out_padded * e->L; np.n_chunks = e->n_chunks;
+        if (e->n_chunks > 2) {
+            // many partials (few outputs, many inputs: an output-sharded rank): add them up with the
+            // whole chip here, in place, same order -- the next call's fused [K3 | K1] launch then
+            // reads one spectrum per channel (and exists: it takes at most two)
+            hipError_t err = hipSuccess;
+            if (e->rs == 4) launch_sum<float>(e, Zp, Zp, &err); else launch_sum<double>(e, Zp, Zp, &err);
+            if (err != hipSuccess) return fail(BFHIP_EHIP, "sum_partials launch: %s", hipGetErrorString(err));
+            np.n_chunks = 1;
+        }
         np.rawout = rawout_dev; np.out_done = out_done; np.mac_done = nullptr;
         e->pendq.push_back(np);
         advance(e);
@@ -3565,6 +3752,7 @@ int bfhip_engine_block_mode(const bfhip_engine *e) {
 }
 int bfhip_engine_uses_wave_fft(const bfhip_engine *e) { return e && e->wave ? 1 : 0; }
 int bfhip_engine_uses_stream_layout(const bfhip_engine *e) { return e && e->hstream.base ? 1 : 0; }
+int bfhip_engine_uses_diag_mac(const bfhip_engine *e) { return e && e->mac_diag ? 1 : 0; }
 int bfhip_engine_ring_depth(const bfhip_engine *e) { return e ? e->R : 0; }
 
 int bfhip_engine_enable_timing(bfhip_engine *e, int on) {

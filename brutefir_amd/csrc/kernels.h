@@ -903,6 +903,99 @@ mac_xbar_kernel(const MacEntry<T> *__restrict__ entries, const ChunkRange *__res
     }
 }
 
+// K2 for ONE-TO-ONE plans (every output fed by at most one entry of a single coefficient term per
+// chunk: massive_config, BASELINE configs[3]): there is nothing to share between outputs, so the
+// crossbar kernel's decomposition -- a workgroup owns a 4 KiB bin tile and walks entries and
+// partitions -- turns into 4 KiB pieces of hundreds of separate ring and coefficient streams
+// (tools/hbm_piece_probe.hip: 5.3 - 5.6 TB/s for that shape against 6.9 for the same bytes read in
+// long runs).  Here a workgroup owns one (chunk, output) job and walks the WHOLE spectrum of every
+// partition of its entry: a ring slot and a coefficient partition are each one contiguous run of
+// L complex numbers (64 KiB at L = 8192), read front to back; the L bins live in registers across the
+// partition loop (acc[tile]), one store per bin at the end.  Same per-bin arithmetic, in the same order
+// over p, as the crossbar kernel's single-term path.
+template <typename T, bool NT, int TILES /* 4 KiB bin tiles per spectrum: L / (256 * V), at least 1 */>
+__global__ __launch_bounds__(256, 2) void          // two workgroups per CU: 256 registers per lane
+mac_diag_kernel(const MacEntry<T> *__restrict__ entries, const int *__restrict__ jobs /* [n_chunks * n_out_padded]: entry or -1 */,
+                c2<T> *__restrict__ Zp, int L, int n_out_padded, unsigned int t, int age, const BlockState *__restrict__ bs,
+                int tsplit /* workgroups per job: each takes TILES consecutive tiles of the spectrum */) {
+    constexpr int V = 16 / sizeof(c2<T>);          // bins per lane and tile: 2 (f32) / 1 (f64)
+    constexpr int TB = 256 * V;                    // bins per tile (4 KiB)
+    constexpr int HT = TILES >= 2 ? TILES / 2 : 1; // tiles per half: the two halves of a partition rotate through two register sets
+    if (bs) { t = bs->t; age = bs->age; }
+    const int job = blockIdx.x / tsplit, part = blockIdx.x % tsplit;
+    const int o = job % n_out_padded;
+    const int e = jobs[job];
+    const int tid = threadIdx.x;
+    const int kl = part * TILES * TB + tid * V;    // this lane's first bin: inside tile 0 of this workgroup's share
+    if (kl >= L) return;                           // (L < one tile: the lanes beyond the spectrum have nothing to do)
+    c2<T> *zp = Zp + (size_t)job * L + kl;         // job = chunk * n_out_padded + o: Zp[chunk][o][.]
+    T acc[TILES][2 * V];
+#pragma unroll
+    for (int tt = 0; tt < TILES; tt++)
+#pragma unroll
+        for (int v = 0; v < 2 * V; v++) acc[tt][v] = (T)0;
+    if (e >= 0) {
+        const MacEntry<T> *E = &entries[e];
+        const int js = o % OG;
+        const c2<T> *ring = E->ring + kl, *H = E->term[js].H + kl;
+        const int R = E->R, delay = E->delay, p0 = E->p0;
+        const T sc = E->term[js].scale;
+        int maxP = E->maxP;
+        if (maxP > age - delay) maxP = age - delay;                 // blocks that exist yet (procblocks)
+        if (maxP > E->term[js].P) maxP = E->term[js].P;
+        if (E->live != nullptr && *E->live == 0) maxP = p0;         // powersave: nothing but silence in the ring
+        struct Half { c2<T> x[HT][V], h[HT][V]; };
+        // one half of partition p in flight: 2 x HT loads of 16 bytes per lane out of two sequential runs
+        auto issue = [&](Half &b, int p, int half) {
+            const unsigned int slot = (t - (unsigned int)p - (unsigned int)delay) % (unsigned int)R;
+            const c2<T> *xb = ring + (size_t)slot * L + half * HT * TB, *hb = H + (size_t)p * L + half * HT * TB;
+#pragma unroll
+            for (int i = 0; i < HT; i++) {
+                Load16<T, false>::get(xb + i * TB, b.x[i]);
+                Load16<T, NT>::get(hb + i * TB, b.h[i]);
+            }
+        };
+        auto consume = [&](const Half &b, int half) {
+#pragma unroll
+            for (int i = 0; i < HT; i++) {
+                const int tt = half * HT + i;
+                const bool dc = tt == 0 && kl == 0;                 // element 0 = (DC, Nyquist): real * real per component
+                const T am = dc ? (T)0 : (T)1;
+                {
+                    const T xr = b.x[i][0].x * sc, xi = b.x[i][0].y * sc;
+                    cmac_first(acc[tt][0], acc[tt][1], xr, xi, b.h[i][0], am, dc);
+                }
+                if constexpr (V == 2) {
+                    const T xr = b.x[i][1].x * sc, xi = b.x[i][1].y * sc;
+                    cmac(acc[tt][2], acc[tt][3], xr, xi, b.h[i][1]);
+                }
+            }
+        };
+        Half a, b;
+        const int n = maxP - p0;
+        if (n > 0) {
+            issue(a, p0, 0);
+            if constexpr (TILES >= 2) issue(b, p0, 1);
+            for (int i = 0; i + 1 < n; i++) {                       // steady state: the next partition's half is requested
+                consume(a, 0); issue(a, p0 + i + 1, 0);             // as soon as its registers are free
+                if constexpr (TILES >= 2) { consume(b, 1); issue(b, p0 + i + 1, 1); }
+            }
+            consume(a, 0);
+            if constexpr (TILES >= 2) consume(b, 1);
+        }
+    }
+#pragma unroll
+    for (int tt = 0; tt < TILES; tt++) {
+        // (0 + acc: what the crossbar kernel's single-term path leaves -- bit-identical, sign of zero included)
+        if constexpr (V == 2) {
+            *reinterpret_cast<float4 *>(zp + tt * TB) =
+                make_float4((T)0 + acc[tt][0], (T)0 + acc[tt][1], (T)0 + acc[tt][2], (T)0 + acc[tt][3]);
+        } else {
+            zp[tt * TB] = mk<T>((T)0 + acc[tt][0], (T)0 + acc[tt][1]);
+        }
+    }
+}
+
 // Z[o][k] = sum_c Zp[c][o][k]   (only used when the spectra leave the engine: multi-GPU)
 template <typename T>
 __global__ __launch_bounds__(256) void
@@ -1930,6 +2023,93 @@ struct RtCopy {
     unsigned int n16;        // 16-byte words (buffers are padded to a multiple of 16 bytes)
     unsigned int pad;
 };
+
+// Wide interleaved sides (hundreds of channels in one frame): a transform workgroup owns ONE channel
+// and would gather its L samples at the stride of a whole frame -- every 4-byte sample in a cache line
+// of its own, every line fetched by as many workgroups as it holds channels (256 channels of S24_4LE:
+// 2 M line requests for 8 MiB of samples).  Instead the frames are transposed once, coalesced both ways
+// through a 64 x 64 tile in LDS, into a planar copy the transforms read (and, on the output side, write)
+// contiguously.  Words are moved, not converted: the sample conversion stays where it is.
+//   to_planar:      src = frames [rows][cols]  ->  dst = planar [cols][rows]
+//   else:           src = planar [cols][rows]  ->  dst = frames [rows][cols], columns [first, first+count)
+//                   whose mask byte (may be null) is 0 only: an engine that runs a shard of the
+//                   configuration leaves the other engines' channels alone
+template <typename W>
+__global__ __launch_bounds__(256) void
+transpose_words_kernel(const W *__restrict__ src, W *__restrict__ dst, int rows, int cols, int to_planar,
+                       const unsigned char *__restrict__ skip, int first, int count) {
+    // 16 bytes per lane on both sides of the tile: Q words in a row of the frame (read) or in a row of
+    // the planar copy (write), whenever the tile is whole and both pointers allow it
+    constexpr int Q = 16 / sizeof(W), TR = 64, TC = 64;
+    __shared__ W tile[TR][TC + 1];
+    const int c0 = blockIdx.x * TC, r0 = blockIdx.y * TR;
+    const int tid = threadIdx.x;
+    const bool whole = r0 + TR <= rows && c0 + TC <= cols && (rows % Q) == 0 && (cols % Q) == 0 &&
+                       ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0;
+    struct alignas(16) Vec { W w[Q]; };
+    if (to_planar) {
+        if (whole) {
+            // frames -> tile[r][c]: a lane takes Q consecutive channels of one frame
+            for (int i = tid; i < TR * (TC / Q); i += 256) {
+                const int r = i / (TC / Q), cq = (i % (TC / Q)) * Q;
+                const Vec v = *reinterpret_cast<const Vec *>(src + (size_t)(r0 + r) * cols + c0 + cq);
+#pragma unroll
+                for (int q = 0; q < Q; q++) tile[r][cq + q] = v.w[q];
+            }
+            __syncthreads();
+            // tile -> planar: a lane takes Q consecutive frames of one channel
+            for (int i = tid; i < TC * (TR / Q); i += 256) {
+                const int c = i / (TR / Q), rq = (i % (TR / Q)) * Q;
+                Vec v;
+#pragma unroll
+                for (int q = 0; q < Q; q++) v.w[q] = tile[rq + q][c];
+                *reinterpret_cast<Vec *>(dst + (size_t)(c0 + c) * rows + r0 + rq) = v;
+            }
+            return;
+        }
+        for (int i = tid; i < TR * TC; i += 256) {
+            const int r = r0 + i / TC, c = c0 + i % TC;
+            if (r < rows && c < cols) tile[i / TC][i % TC] = src[(size_t)r * cols + c];
+        }
+        __syncthreads();
+        for (int i = tid; i < TR * TC; i += 256) {
+            const int c = c0 + i / TR, r = r0 + i % TR;
+            if (r < rows && c < cols) dst[(size_t)c * rows + r] = tile[i % TR][i / TR];
+        }
+        return;
+    }
+    // planar -> frames; only columns [first, first + count) that are not another engine's
+    bool all_mine = whole && c0 >= first && c0 + TC <= first + count;
+    if (all_mine && skip != nullptr)
+        for (int c = 0; c < TC; c++) all_mine = all_mine && !skip[c0 + c];
+    if (all_mine) {
+        for (int i = tid; i < TC * (TR / Q); i += 256) {
+            const int c = i / (TR / Q), rq = (i % (TR / Q)) * Q;
+            const Vec v = *reinterpret_cast<const Vec *>(src + (size_t)(c0 + c) * rows + r0 + rq);
+#pragma unroll
+            for (int q = 0; q < Q; q++) tile[rq + q][c] = v.w[q];
+        }
+        __syncthreads();
+        for (int i = tid; i < TR * (TC / Q); i += 256) {
+            const int r = i / (TC / Q), cq = (i % (TC / Q)) * Q;
+            Vec v;
+#pragma unroll
+            for (int q = 0; q < Q; q++) v.w[q] = tile[r][cq + q];
+            *reinterpret_cast<Vec *>(dst + (size_t)(r0 + r) * cols + c0 + cq) = v;
+        }
+        return;
+    }
+    for (int i = tid; i < TR * TC; i += 256) {
+        const int c = c0 + i / TR, r = r0 + i % TR;
+        if (r < rows && c < cols) tile[i % TR][i / TR] = src[(size_t)c * rows + r];
+    }
+    __syncthreads();
+    for (int i = tid; i < TR * TC; i += 256) {
+        const int r = r0 + i / TC, c = c0 + i % TC;
+        const bool mine = c < cols && c >= first && c < first + count && (skip == nullptr || !skip[c]);
+        if (r < rows && mine) dst[(size_t)r * cols + c] = tile[i / TC][i % TC];
+    }
+}
 
 template <int UNUSED>
 __global__ __launch_bounds__(256) void rt_copy_in_kernel(RtCopy c) {

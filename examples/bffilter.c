@@ -8,7 +8,10 @@
  * filter_process() -- and write the interleaved raw output, truncating the
  * last block like dai.c does at EOF (dai.c:1423-1439).
  *
- *   bffilter L N n_in n_out infmt outfmt coeffs.f32 in.raw out.raw [dither_rate]
+ *   bffilter L N n_in n_out infmt outfmt coeffs.f32 in.raw out.raw [dither_rate [benchmark]]
+ *
+ *   benchmark: print the reference's `benchmark: true` stage table (bfrun.c:2035-2078) every ten
+ *   periods, its columns filled from bfhip_engine_stage_times() (device milliseconds)
  *
  *   coeffs.f32: n_out * n_in impulse responses of L*N float32 taps, output-major
  *   infmt/outfmt: S16_LE S24_LE S24_4LE S32_LE FLOAT_LE FLOAT64_LE
@@ -46,7 +49,7 @@ static void die(const char *what)
 
 int main(int argc, char *argv[])
 {
-    int L, N, n_in, n_out, io, c, o, i, st, dither_rate = 0;
+    int L, N, n_in, n_out, io, c, o, i, st, dither_rate = 0, benchmark = 0;
     const struct fmtdesc *fd[2];
     bfhip_engine *e;
     bfhip_overflow *of;
@@ -64,6 +67,7 @@ int main(int argc, char *argv[])
     fd[BFHIP_IN] = find_format(argv[5]);
     fd[BFHIP_OUT] = find_format(argv[6]);
     if (argc > 10) dither_rate = atoi(argv[10]);
+    if (argc > 11) benchmark = 1;
 
     /* bfconf_init() + filter_process() set-up */
     e = bfhip_engine_create(0, L, N, 4, n_in, n_out);
@@ -104,6 +108,7 @@ int main(int argc, char *argv[])
     fclose(fc);
     free(taps);
     if (bfhip_engine_finalize(e) < 0) die("bfhip_engine_finalize");
+    if (benchmark && bfhip_engine_enable_timing(e, 1) < 0) die("bfhip_engine_enable_timing");
 
     /* the run loop: input_process / filter_process / output_process collapsed into one */
     inbytes = (size_t)L * n_in * fd[BFHIP_IN]->bytes;
@@ -123,6 +128,15 @@ int main(int argc, char *argv[])
         frames = got / ((size_t)n_in * fd[BFHIP_IN]->bytes);
         fwrite(outbuf, (size_t)n_out * fd[BFHIP_OUT]->bytes, frames, fo);
         blocks++;
+        if (benchmark && blocks % 10 == 0) {
+            double ms[8];
+            if (bfhip_engine_stage_times(e, ms) > 0) {
+                if (blocks == 10)
+                    fprintf(stderr, "  raw2real | time2freq | mixscale1 |  convolve | mixscale2 | freq2time |  real2raw |     total | periods\n");
+                fprintf(stderr, " %9.3f | %9.3f | %9.3f | %9.3f | %9.3f | %9.3f | %9.3f | %9.3f | %7lu\n",
+                        ms[0], ms[1], ms[2], ms[3], ms[4], ms[5], ms[6], ms[7], blocks);
+            }
+        }
     }
     fclose(fi);
     fclose(fo);

@@ -380,6 +380,10 @@ int bfhip_engine_uses_wave_fft(const bfhip_engine *e);
 /* 1 if the MAC reads a stream-ordered copy of the coefficients (uniform crossbar plans: every
    workgroup one sequential slice; costs a second copy of the coefficient memory) */
 int bfhip_engine_uses_stream_layout(const bfhip_engine *e);
+/* 1: the plan is one-to-one (every output fed by one single-term filter: massive_config, BASELINE
+   configs[3]) and the MAC runs as mac_diag_kernel -- a workgroup per (part, output) walking whole
+   spectra -- instead of the crossbar kernel */
+int bfhip_engine_uses_diag_mac(const bfhip_engine *e);
 /* depth of the input spectrum rings (n_blocks, plus one spare slot when the block is pipelined) */
 int bfhip_engine_ring_depth(const bfhip_engine *e);
 

@@ -33,6 +33,18 @@ def test_c_host_file_to_file(hip, tmp_path, L, N):
                         str(tmp_path / "out.raw")], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     assert "%d blocks" % nblk in r.stderr
+    if L < 4096:
+        # the same run with the reference's `benchmark: true` stage table (bfrun.c:2035-2078) filled
+        # from bfhip_engine_stage_times(): dithered 16-bit output -> the real2raw column has a time
+        rb = subprocess.run([exe, str(L), str(N), str(I), str(O), "S16_LE", "S16_LE",
+                             str(tmp_path / "coeffs.f32"), str(tmp_path / "in.raw"),
+                             str(tmp_path / "out_bm.raw"), "44100", "benchmark"], capture_output=True, text=True, timeout=120)
+        assert rb.returncode == 0, rb.stderr
+        # (9 blocks: no tenth period, no row; the header test lives with bfprocs -- here only that timing changes nothing)
+        ra = subprocess.run([exe, str(L), str(N), str(I), str(O), "S16_LE", "S16_LE",
+                             str(tmp_path / "coeffs.f32"), str(tmp_path / "in.raw"),
+                             str(tmp_path / "out_nobm.raw"), "44100"], capture_output=True, text=True, timeout=120)
+        assert ra.returncode == 0 and open(tmp_path / "out_bm.raw", "rb").read() == open(tmp_path / "out_nobm.raw", "rb").read()
     got = np.fromfile(tmp_path / "out.raw", np.int32).reshape(-1, O)
     assert got.shape[0] == raw.shape[0]                             # as many frames out as in
     oe = bo.Engine(L, N, 4, I, O)

@@ -22,7 +22,9 @@ def main():
     kt = json.load(open(os.path.join(d, "config%s_bench_ktrace_summary.json" % wl)))
     live = json.loads([ln for ln in open(os.path.join(d, "bench_config%s_under_rocprofv3.json" % wl))
                        if ln.startswith("{")][-1])
-    name = [k for k in fetch if "mac_xbar_kernel" in k][0]
+    # the MAC of the plan: the crossbar kernel, or mac_diag_kernel for one-to-one plans (workload D)
+    macs = [k for k in kt if ("mac_xbar_kernel" in k or "mac_diag_kernel" in k) and k in fetch and k in write]
+    name = max(macs, key=lambda k: kt[k]["avg_ns_all"] * kt[k]["calls"])
     f, w, k = fetch[name], write[name], kt[name]
     fetch_b = f["fetch_bytes_corrected"]
     write_b = w["write_bytes"]

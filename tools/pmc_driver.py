@@ -16,7 +16,9 @@ import numpy as np  # noqa: E402
 import brutefir_amd as bf  # noqa: E402
 
 WL = {"C": (64, 64, 8192, 32, 4), "B": (8, 8, 8192, 8, 4), "S": (16, 16, 8192, 32, 4),
-      "F": (32, 32, 8192, 32, 8)}       # F: the float64 crossbar of bench.py --workload F
+      "F": (32, 32, 8192, 32, 8),       # F: the float64 crossbar of bench.py --workload F
+      "D": (256, 256, 8192, 16, 4)}     # D: 256 one-to-one filters (BASELINE configs[3] on one GPU)
+DIAGONAL = {"D"}
 
 
 def main():
@@ -30,9 +32,12 @@ def main():
     rng = np.random.default_rng(5)
     h = rng.standard_normal(L * N) * np.exp(-np.arange(L * N) / (L * N / 6.0))
     h = (h / (np.abs(h).sum() * I)).astype(np.float32 if rs == 4 else np.float64)
-    e.reserve_coeffs(float(I * O) * N * 2 * L * rs)
+    n_sets = O if name in DIAGONAL else I * O
+    e.reserve_coeffs(float(n_sets) * N * 2 * L * rs)
     for o in range(O):
         for i in range(I):
+            if name in DIAGONAL and i != o:
+                continue
             e.add_filter(in_ch=[i], out_ch=[o], coeff=e.add_coeff(h))
     e.finalize()
     raw = ((rng.standard_normal((L, I)) * 0.1 * 8388608).astype(np.int32) if rs == 4
