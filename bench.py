@@ -372,6 +372,10 @@ def main():
                          "I/N inputs, one RCCL reduce-scatter of the partial output spectra per block); "
                          "output = the reference's own process rule (bfconf.c:2893-2931: rank r owns O/N outputs "
                          "and every filter feeding them, transforms ALL inputs itself, no collective at all)")
+    ap.add_argument("--pairs", action="store_true",
+                    help="INFORMATIVE, never the headline: two blocks per pass over the coefficients "
+                         "(bfhip_engine_block_pair_dev) -- what a host with two periods in hand gets; one period "
+                         "of extra I/O delay, the same output bits")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the end-to-end check of the timed configuration's outputs (after the timed region)")
@@ -476,6 +480,10 @@ def main():
     for c in range(co if out_sharded else O):
         eng.set_format(bf.OUT, c, outfmts[fo + c] if out_sharded else outfmts[c])
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    if args.pairs:
+        if shards != 1 or args.host_io or args.steps % 2 or args.warmup % 2:
+            raise SystemExit("bench.py: --pairs is a single-GPU device-buffer mode with even --steps / --warmup")
+        eng.enable_pairs(True)
     taps = L * N
     tdt = torch.float32 if rs == 4 else torch.float64
     my_outs = range(fo, fo + co) if out_sharded else range(O)
@@ -547,7 +555,8 @@ def main():
 
     # which device buffers block k reads and writes: the pool and the one output buffer while timing,
     # per-block buffers during the verification pass (same step loop, same launches)
-    bufs = {"in": lambda k: raw_in[k % n_pool], "out": lambda k: raw_out}
+    raw_out2 = torch.zeros_like(raw_out) if args.pairs else None
+    bufs = {"in": lambda k: raw_in[k % n_pool], "out": lambda k: raw_out if (k % 2 == 0 or not args.pairs) else raw_out2}
 
     def step(k):
         src = bufs["in"](k)
@@ -560,6 +569,9 @@ def main():
                     if _lib.bfhip_engine_rt_wait(eng.h, _out_p, None) < 0:
                         raise RuntimeError(_lib.bfhip_last_error().decode())
                     host_inflight[0] -= 1
+            elif args.pairs:
+                if k % 2 == 1:                       # blocks k - 1 and k: one pass over the coefficients
+                    eng.block_pair_dev(bufs["in"](k - 1), bufs["out"](k - 1), src, bufs["out"](k))
             else:
                 eng.block_dev(src, bufs["out"](k))
             return
@@ -653,7 +665,7 @@ def main():
         torch.fft (the impulse responses are regenerated from their seeds on the device)."""
         timed[0] = False
         k0 = args.warmup + args.steps
-        nb = 2 * N + 1
+        nb = 2 * N + 1 + (1 if args.pairs else 0)       # (pairs: an even number of blocks)
         probe = list(range(I))
         if rehearse > 1 and not out_sharded:
             probe = list(range(fi, fi + ci))    # one input-sharded rank alone: only its own inputs reach its outputs
@@ -668,7 +680,7 @@ def main():
         drain()
         st = eng.sync()
         torch.cuda.synchronize()
-        got = torch.cat(vout[N:], dim=0)[:, fo:fo + co].to(torch.float64)       # [(N+1) L][co]
+        got = torch.cat(vout[N:2 * N + 1], dim=0)[:, fo:fo + co].to(torch.float64)       # [(N+1) L][co]
         n_y = (N + 1) * L
         n_fft = 1
         while n_fft < L + taps:
@@ -746,6 +758,8 @@ def main():
                        % (rehearse, "output-sharded: no collective exists" if out_sharded
                           else "RCCL reduce-scatter on a one-rank communicator" if rccl_rehearsal
                           else "input-sharded, collective replaced by a copy")) if rehearse > 1
+                      else ("INFORMATIVE (not the headline): block pairs -- two blocks per pass over the coefficients, "
+                            "one period of extra I/O delay: filtered samples/sec") if args.pairs
                       else (BASELINE_METRIC if args.workload == "C" else "filtered samples/sec"),
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
@@ -789,6 +803,17 @@ def main():
                 traffic_src = tj.get("source_hash")
                 traffic_stale = traffic_src != src_hash
             rf = mac_roofline(tm, alg["mac"])
+            if args.pairs:
+                # one paired launch: the coefficients and the rings once, one more ring slot per input,
+                # a second set of output spectra
+                Cb = L * 2 * rs
+                pair_bytes = alg["mac"] + Cb * (ci + O)
+                mac_s = tm["mac_ms"] * 1e-3
+                rf.update({"kernel": "mac_xbar2_kernel", "algorithmic_bytes_per_launch": pair_bytes,
+                           "achieved": pair_bytes / mac_s / 1e9 if mac_s > 0 else None,
+                           "frac": pair_bytes / mac_s / 1e9 / HBM_PEAK_GBS if mac_s > 0 else None,
+                           "blocks_per_launch": 2, "paired_launches": eng.pair_launches})
+                traffic = None
             rf.update({"traffic": traffic, "traffic_stale": traffic_stale, "traffic_source_hash": traffic_src,
                        "launches": args.steps, "fft_in_ms": tm["fft_in_ms"], "ifft_out_ms": tm["ifft_out_ms"]})
             if eng.block_mode in (2, 3):

@@ -137,6 +137,10 @@ def lib():
     L.bfhip_engine_uses_wave_fft.argtypes = [vp]
     L.bfhip_engine_uses_stream_layout.argtypes = [vp]
     L.bfhip_engine_uses_diag_mac.argtypes = [vp]
+    L.bfhip_engine_enable_pairs.argtypes = [vp, ci]
+    L.bfhip_engine_block_pair_dev.argtypes = [vp, vp, vp, vp, vp]
+    L.bfhip_engine_pair_launches.argtypes = [vp]
+    L.bfhip_engine_pair_launches.restype = C.c_ulonglong
     L.bfhip_engine_enable_timing.argtypes = [vp, ci]
     L.bfhip_engine_get_timing.argtypes = [vp, dp]
     L.bfhip_engine_algorithmic_bytes.argtypes = [vp, dp]
@@ -368,6 +372,17 @@ class Engine:
 
     def block_dev(self, rawin_dev, rawout_dev):
         _check(lib().bfhip_engine_block_dev(self.h, _ptr(rawin_dev), _ptr(rawout_dev)))
+
+    def enable_pairs(self, on=True):
+        _check(lib().bfhip_engine_enable_pairs(self.h, int(on)))
+
+    def block_pair_dev(self, rawin0_dev, rawout0_dev, rawin1_dev, rawout1_dev):
+        """two consecutive blocks, one pass over the coefficients (after enable_pairs before finalize)"""
+        _check(lib().bfhip_engine_block_pair_dev(self.h, _ptr(rawin0_dev), _ptr(rawout0_dev), _ptr(rawin1_dev), _ptr(rawout1_dev)))
+
+    @property
+    def pair_launches(self):
+        return int(lib().bfhip_engine_pair_launches(self.h))
 
     def block_dev_ev(self, rawin_dev, rawout_dev, in_ready=None, out_done=None):
         """in_ready / out_done: hipEvent_t handles (ints), e.g. torch.cuda.Event().cuda_event"""

@@ -424,6 +424,9 @@ struct bfhip_engine {
     bool wide[2] = {false, false};
     uint8_t *d_planar[2] = {nullptr, nullptr};     // [n_phys][L] words of the side's sample size
     unsigned char *d_phys_skip = nullptr;          // [n_phys out] 1 = another engine's channel (shards)
+    // two blocks per pass over the coefficients (bfhip_engine_enable_pairs / bfhip_engine_block_pair_dev)
+    bool pairs = false;
+    unsigned long long n_pair_launches = 0;
     bool all_dense = false;        // every MAC entry takes the crossbar path
     // one-to-one plans (every output fed by at most one single-term entry per chunk): mac_diag_kernel,
     // one workgroup per (chunk, output) walking whole spectra (BFHIP_MAC_DIAG=0 keeps the crossbar kernel)
@@ -765,6 +768,16 @@ void launch_mac(bfhip_engine *e, void *Zp, hipError_t *err) {
     else if (e->mac_unroll == 1) BFHIP_LAUNCH_MAC(true, 1);
     else BFHIP_LAUNCH_MAC(true, 2);
 #undef BFHIP_LAUNCH_MAC
+    *err = hipGetLastError();
+}
+
+template <typename T>
+void launch_mac2(bfhip_engine *e, void *Zp0, void *Zp1, hipError_t *err) {
+    const int n_tc = e->n_tiles * e->n_chunks;
+    const int grid = ((n_tc + 7) / 8) * e->n_groups * 8;
+    hipLaunchKernelGGL((mac_xbar2_kernel<T, true>), dim3(grid), dim3(e->mac_threads), 0, e->ls,
+                       (const MacEntry<T> *)e->d_entries, (const ChunkRange *)e->d_chunks, (c2<T> *)Zp0, (c2<T> *)Zp1,
+                       e->L, e->n_out_padded, e->n_groups, e->n_chunks, n_tc, e->blockcounter, e->hstream);
     *err = hipGetLastError();
 }
 
@@ -1490,7 +1503,7 @@ int build_plan_t(bfhip_engine *e) {
         if (e->d_Zp3) (void)hipFree(e->d_Zp3);
         e->d_Zp2 = nullptr; e->d_Zp3 = nullptr;
         HIPCHK(dev_alloc(&e->d_Zp, zb));
-        if (e->pipelined || e->defer_out) HIPCHK(dev_alloc(&e->d_Zp2, zb));
+        if (e->pipelined || e->defer_out || e->pairs) HIPCHK(dev_alloc(&e->d_Zp2, zb));
         if (e->pipe2) HIPCHK(dev_alloc(&e->d_Zp3, zb));
         e->zp_bytes = zb;
     }
@@ -1840,12 +1853,12 @@ int post_outputs(bfhip_engine *e, void *rawout_dev, int first, int count) {
     return p1 < p0 ? BFHIP_OK : launch_transpose(e, 1, e->d_planar[1], rawout_dev, 0, p0, p1 - p0 + 1);
 }
 
-int do_inputs(bfhip_engine *e, const void *rawin_dev) {
+int do_inputs(bfhip_engine *e, const void *rawin_dev, unsigned int ahead = 0u /* blocks ahead of the counter (block pairs) */) {
     { int rv = pre_inputs(e, rawin_dev); if (rv != BFHIP_OK) return rv; }
     { int rv = do_vin(e, rawin_dev); if (rv != BFHIP_OK) return rv; }
     { int rv = do_subdelay(e, 0, rawin_dev); if (rv != BFHIP_OK) return rv; }
     hipError_t err = hipSuccess;
-    const int slot = (int)(e->blockcounter % (unsigned int)e->R);
+    const int slot = (int)((e->blockcounter + ahead) % (unsigned int)e->R);
     if (e->big) { int rr = big_reserve(e, (size_t)e->n_ch[0]); if (rr != BFHIP_OK) return rr; }
     if (e->big) DISPATCH_BIG(launch_fft_in_big, e, (const uint8_t *)rawin_dev, slot, &err);
     else if (e->wave) { DISPATCH_WAVE(launch_fft_in_wave, e, (const uint8_t *)rawin_dev, slot, &err) }
@@ -2903,7 +2916,9 @@ static int finalize_impl(bfhip_engine *e) {
         e->pipe2 = e->pipelined && plain;
         if (const char *env = getenv("BFHIP_PIPE2")) e->pipe2 = e->pipe2 && atoi(env) != 0;
     }
-    e->R = e->pipelined ? e->N + 1 : e->N;
+    if (e->pairs) { e->pipelined = false; e->pipe2 = false; }       // block pairs run on the one main stream
+    // (a pair needs the spare ring slot too: block t + 1 is transformed before the MAC reads block t - N + 1)
+    e->R = (e->pipelined || e->pairs) ? e->N + 1 : e->N;
     {
         // the shared rings are R deep, the private ones N: the counter wraps by a multiple of both
         const unsigned long long period = e->R == e->N ? (unsigned long long)e->N : (unsigned long long)e->N * e->R;
@@ -3444,6 +3459,54 @@ static int block_dev_impl(bfhip_engine *e, const void *rawin_dev, void *rawout_d
     advance(e);
     return BFHIP_OK;
 }
+
+int bfhip_engine_enable_pairs(bfhip_engine *e, int on) {
+    if (!e) return fail(BFHIP_EINVAL, "null engine");
+    if (e->finalized) return fail(BFHIP_ESTATE, "enable_pairs after finalize");
+    e->pairs = on != 0;
+    return BFHIP_OK;
+}
+
+// Two consecutive blocks, ONE pass over the coefficients (mac_xbar2_kernel).  Falls back to two
+// single blocks whenever the plan is not a plain uniform crossbar or its rings are not full yet:
+// the outputs are the same bits either way.
+int bfhip_engine_block_pair_dev(bfhip_engine *e, const void *rawin0_dev, void *rawout0_dev,
+                                const void *rawin1_dev, void *rawout1_dev) {
+    int r = ensure_ready(e);
+    if (r != BFHIP_OK) return r;
+    if (!rawin0_dev || !rawout0_dev || !rawin1_dev || !rawout1_dev) return fail(BFHIP_EINVAL, "block_pair_dev: null buffer");
+    bool plain = e->pairs && e->all_dense && !e->mac_diag && e->mac_nt && e->mac_unroll == 0 && !e->any_fading &&
+                 !e->has_vchan && !e->big && !e->rt.on && e->d_Zp2 != nullptr && e->blocks_done >= (unsigned long long)e->N;
+    for (auto &lj : e->level_jobs) plain = plain && !lj.n_fill && !lj.n_filt && !lj.n_fade;
+    if (!plain) {
+        if ((r = bfhip_engine_block_dev(e, rawin0_dev, rawout0_dev)) != BFHIP_OK) return r;
+        return bfhip_engine_block_dev(e, rawin1_dev, rawout1_dev);
+    }
+    if ((r = flush_pending(e)) != BFHIP_OK) return r;          // an output owed by a single block goes first
+    LsGuard guard{e};
+    e->ls = e->stream;
+    timing_begin(e);
+    if ((r = record(e, 0)) != BFHIP_OK) return r;
+    if ((r = do_inputs(e, rawin0_dev, 0u)) != BFHIP_OK) return r;
+    if ((r = do_inputs(e, rawin1_dev, 1u)) != BFHIP_OK) return r;
+    if ((r = record(e, 1)) != BFHIP_OK) return r;
+    if ((r = record(e, 2)) != BFHIP_OK) return r;
+    hipError_t err = hipSuccess;
+    if (e->rs == 4) launch_mac2<float>(e, e->d_Zp, e->d_Zp2, &err); else launch_mac2<double>(e, e->d_Zp, e->d_Zp2, &err);
+    if (err != hipSuccess) return fail(BFHIP_EHIP, "mac2 launch: %s", hipGetErrorString(err));
+    if ((r = record(e, 3)) != BFHIP_OK) return r;
+    if ((r = record(e, 4)) != BFHIP_OK) return r;
+    const size_t stride = (size_t)e->n_out_padded * e->L;
+    if ((r = do_outputs(e, e->d_Zp, stride, e->n_chunks, 0, e->n_ch[1], rawout0_dev)) != BFHIP_OK) return r;
+    if ((r = do_outputs(e, e->d_Zp2, stride, e->n_chunks, 0, e->n_ch[1], rawout1_dev)) != BFHIP_OK) return r;
+    if ((r = record(e, 5)) != BFHIP_OK) return r;
+    e->n_pair_launches++;
+    advance(e);
+    advance(e);
+    return BFHIP_OK;
+}
+
+unsigned long long bfhip_engine_pair_launches(const bfhip_engine *e) { return e ? e->n_pair_launches : 0ull; }
 
 int bfhip_engine_flush(bfhip_engine *e) {
     if (!e || !e->finalized) return fail(BFHIP_ESTATE, "engine not finalized");

@@ -903,6 +903,119 @@ mac_xbar_kernel(const MacEntry<T> *__restrict__ entries, const ChunkRange *__res
     }
 }
 
+// K2 over TWO consecutive blocks in one pass over the coefficients (uniform crossbars only: every
+// entry OG coefficient terms of full length).  The MAC of a large crossbar is nothing but the
+// coefficient stream -- config C reads 8 GiB per block to produce 2 MiB -- so a host that has two
+// periods in hand (the blocking-I/O topology, which keeps two in flight anyway) gets two blocks for
+// the traffic of one:   Z_t[o] += X_(t-p) H_p   and   Z_(t+1)[o] += X_(t+1-p) H_p   share H_p, and
+// X_(t+1-p) is the ring value the previous partition used for block t (one ring load per
+// partition, kept in registers).  Per block the products are accumulated in exactly the order of
+// mac_xbar_kernel: the two outputs are bit-identical to two single-block launches.
+template <typename T, bool NT>
+__global__ __launch_bounds__(256) void
+mac_xbar2_kernel(const MacEntry<T> *__restrict__ entries, const ChunkRange *__restrict__ chunks,
+                 c2<T> *__restrict__ Zp0, c2<T> *__restrict__ Zp1, int L, int n_out_padded, int n_groups, int n_chunks,
+                 int n_tc, unsigned int t /* counter of the FIRST block; the rings hold t + 1 already */, StreamLayout sl) {
+    constexpr int V = 16 / sizeof(c2<T>);
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, local = bid >> 3;
+    const int group = local % n_groups;
+    const int tc = (local / n_groups) * 8 + xcd;
+    if (tc >= n_tc) return;
+    const int tile = tc / n_chunks, chunk = tc % n_chunks;
+    const int k0 = (tile * (int)blockDim.x + (int)threadIdx.x) * V;
+    if (k0 >= L) return;
+    const bool dc = (k0 == 0);
+    const T am = dc ? (T)0 : (T)1;
+
+    T acc0[OG][2 * V], acc1[OG][2 * V];
+#pragma unroll
+    for (int j = 0; j < OG; j++)
+#pragma unroll
+        for (int v = 0; v < 2 * V; v++) { acc0[j][v] = (T)0; acc1[j][v] = (T)0; }
+
+    const ChunkRange cr = chunks[group * n_chunks + chunk];
+    for (int e = cr.begin; e < cr.end; e++) {
+        const MacEntry<T> *E = &entries[e];
+        const c2<T> *ring = E->ring;
+        const int R = E->R, delay = E->delay, p0 = E->p0, maxP = E->maxP;
+        if (E->live != nullptr && *E->live == 0) continue;           // powersave: nothing but silence in this ring
+        const c2<T> *Hs[OG];
+        T sc[OG];
+#pragma unroll
+        for (int j = 0; j < OG; j++) { Hs[j] = E->term[j].H; sc[j] = E->term[j].scale; }
+        unsigned int hstep = (unsigned int)L * (unsigned int)sizeof(c2<T>);
+        unsigned int hlane = (unsigned int)k0 * (unsigned int)sizeof(c2<T>);
+        if (sl.base != nullptr) {
+            const unsigned char *wg = sl.base + (unsigned long long)bid * sl.slice + (unsigned int)(e - cr.begin) * sl.entry_bytes;
+#pragma unroll
+            for (int j = 0; j < OG; j++) Hs[j] = (const c2<T> *)(wg + (unsigned int)j * sl.chunk);
+            hstep = (unsigned int)OG * sl.chunk;
+            hlane = (unsigned int)threadIdx.x * 16u;
+        }
+        struct Stage { c2<T> x[V]; c2<T> h[OG][V]; };
+        auto ring_at = [&](unsigned int blk, c2<T> *x) {              // X_blk: ring slot (blk - delay) mod R
+            const unsigned int slot = (blk - (unsigned int)delay) % (unsigned int)R;
+            Load16<T, false>::get((const c2<T> *)((const char *)ring + (slot * (unsigned int)L + (unsigned int)k0) * (unsigned int)sizeof(c2<T>)), x);
+        };
+        auto issue = [&](Stage &st, int p) {
+            ring_at(t - (unsigned int)p, st.x);
+            const unsigned int hoff = (unsigned int)p * hstep + hlane;
+#pragma unroll
+            for (int j = 0; j < OG; j++) Load16<T, NT>::get((const c2<T> *)((const char *)Hs[j] + hoff), st.h[j]);
+        };
+        c2<T> xn[V];                                                    // X_(t+1-p): what block t+1 multiplies H_p with
+        auto consume = [&](const Stage &st) {
+#pragma unroll
+            for (int j = 0; j < OG; j++) {
+                {
+                    const T xr = st.x[0].x * sc[j], xi = st.x[0].y * sc[j];
+                    cmac_first(acc0[j][0], acc0[j][1], xr, xi, st.h[j][0], am, dc);
+                    const T yr = xn[0].x * sc[j], yi = xn[0].y * sc[j];
+                    cmac_first(acc1[j][0], acc1[j][1], yr, yi, st.h[j][0], am, dc);
+                }
+                if constexpr (V == 2) {
+                    const T xr = st.x[1].x * sc[j], xi = st.x[1].y * sc[j];
+                    cmac(acc0[j][2], acc0[j][3], xr, xi, st.h[j][1]);
+                    const T yr = xn[1].x * sc[j], yi = xn[1].y * sc[j];
+                    cmac(acc1[j][2], acc1[j][3], yr, yi, st.h[j][1]);
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < V; v++) xn[v] = st.x[v];               // X_(t-p) is X_(t+1-(p+1))
+        };
+        const int n = maxP - p0;
+        Stage s0, s1, s2;
+        if (n >= 1) { ring_at(t + 1u - (unsigned int)p0, xn); issue(s0, p0); }
+        if (n >= 2) issue(s1, p0 + 1);
+        if (n >= 3) issue(s2, p0 + 2);
+        int i = 0;
+        for (; i + 6 <= n; i += 3) {
+            consume(s0); issue(s0, p0 + i + 3);
+            consume(s1); issue(s1, p0 + i + 4);
+            consume(s2); issue(s2, p0 + i + 5);
+        }
+        for (; i + 3 <= n; i += 3) {
+            consume(s0); if (i + 3 < n) issue(s0, p0 + i + 3);
+            consume(s1); if (i + 4 < n) issue(s1, p0 + i + 4);
+            consume(s2); if (i + 5 < n) issue(s2, p0 + i + 5);
+        }
+        if (i < n) consume(s0);
+        if (i + 1 < n) consume(s1);
+    }
+    const size_t zoff = ((size_t)chunk * n_out_padded + (size_t)group * OG) * L + k0;
+#pragma unroll
+    for (int j = 0; j < OG; j++) {
+        if constexpr (V == 2) {
+            *reinterpret_cast<float4 *>(Zp0 + zoff + (size_t)j * L) = make_float4(acc0[j][0], acc0[j][1], acc0[j][2], acc0[j][3]);
+            *reinterpret_cast<float4 *>(Zp1 + zoff + (size_t)j * L) = make_float4(acc1[j][0], acc1[j][1], acc1[j][2], acc1[j][3]);
+        } else {
+            Zp0[zoff + (size_t)j * L] = mk<T>(acc0[j][0], acc0[j][1]);
+            Zp1[zoff + (size_t)j * L] = mk<T>(acc1[j][0], acc1[j][1]);
+        }
+    }
+}
+
 // K2 for ONE-TO-ONE plans (every output fed by at most one entry of a single coefficient term per
 // chunk: massive_config, BASELINE configs[3]): there is nothing to share between outputs, so the
 // crossbar kernel's decomposition -- a workgroup owns a 4 KiB bin tile and walks entries and
@@ -1567,7 +1680,9 @@ ifft_out_wave_body(int zi /* index into Zp's channel axis */, unsigned char *sme
         if (tid == 0) t0 = zc[0];
     }
     WaveTw<T, LOG2L> twr;
-    twr.prefetch(tw);
+    // (float64: the 18 pass twiddles are 72 registers -- requested only once the spectra have been
+    // folded into LDS, or the kernel spills; their latency then hides behind the barrier and pass 0)
+    if constexpr (sizeof(T) == 4) twr.prefetch(tw);
 #pragma unroll
     for (int i = 0; i < QU; i++) { const int k = 1 + tid + i * NT; uw[i] = tw[k <= L / 2 ? k : 0]; }
     const DevFormat f = fmt[ch];
@@ -1604,6 +1719,7 @@ ifft_out_wave_body(int zi /* index into Zp's channel axis */, unsigned char *sme
         }
     }
     BF_PROBE(2);
+    if constexpr (sizeof(T) == 8) twr.prefetch(tw);
     __syncthreads();
     wave_p0_lds<T, LOG2L, true>(s);
     BF_PROBE(4);

@@ -255,6 +255,20 @@ int bfhip_engine_block(bfhip_engine *e, const void *rawin, void *rawout,
    the forward transforms of the next into one launch on one stream.  BFHIP_OVERLAP=0/1 in the
    environment moves the automatic choice; bfhip_engine_set_overlap decides it. */
 int bfhip_engine_block_dev(bfhip_engine *e, const void *rawin_dev, void *rawout_dev);
+/* TWO consecutive blocks with ONE pass over the coefficients (exploratory; bench.py --pairs reports it
+   as an informative line, never as the headline).  The MAC of a large crossbar is nothing but the
+   coefficient stream -- config C reads 8 GiB per block -- and a host that has two periods in hand
+   (the blocking-I/O topology keeps two in flight anyway, at one period of extra I/O delay) can
+   have both multiplied while each coefficient tile is in registers once.  Needs
+   bfhip_engine_enable_pairs(e, 1) BEFORE finalize (one spare ring slot, a second partial-sum
+   buffer).  Plans that are not a plain uniform crossbar, and the first N blocks of a run, go through
+   two single blocks instead: rawout0 / rawout1 hold the same bits either way
+   (tests/test_gpu_pairs.py).  Same ordering contract as bfhip_engine_block_dev, both outputs complete
+   in stream order behind the call.  bfhip_engine_pair_launches: how many calls took the paired path. */
+int bfhip_engine_enable_pairs(bfhip_engine *e, int on);
+int bfhip_engine_block_pair_dev(bfhip_engine *e, const void *rawin0_dev, void *rawout0_dev,
+                                const void *rawin1_dev, void *rawout1_dev);
+unsigned long long bfhip_engine_pair_launches(const bfhip_engine *e);
 /* ORDERING CONTRACT of bfhip_engine_block_dev.  The engine launches on streams of its own (K1 of
    a pipelined block even on a side stream that does NOT follow the stream given to
    bfhip_engine_set_stream), so stream order alone protects nothing:

@@ -138,7 +138,7 @@ def test_no_entry_point_crashes_on_a_null_handle():
     assert len(calls) >= 70
     neutral = {"bfhip_engine_output_lag", "bfhip_engine_blockcounter", "bfhip_engine_uses_wave_fft",
                "bfhip_engine_uses_stream_layout", "bfhip_engine_ring_depth", "bfhip_nupc_taps", "bfhip_nupc_latency",
-               "bfhip_engine_coeff_is_resident", "bfhip_engine_output_is_active", "bfhip_engine_uses_diag_mac"}
+               "bfhip_engine_coeff_is_resident", "bfhip_engine_output_is_active", "bfhip_engine_uses_diag_mac", "bfhip_engine_pair_launches"}
     for name, ret in calls.items():
         if ret == "void":
             continue
