@@ -450,6 +450,12 @@ struct bfhip_engine {
         unsigned int bs_t = 0;                      // what d_bs->t holds
         bool bs_synced = false;
         unsigned long long n_graph = 0, n_direct = 0, n_capture = 0;
+        // what rt_wait last wrote into the caller's overflow array: an entry that differs from it
+        // next time was changed by the HOST (bf_reset_peak, bfrun.c: the CLI's peak reset) and
+        // becomes the device's state for that output
+        std::vector<DevOverflow> last_over;
+        std::vector<unsigned long long> over_from;
+        bool last_valid = false;
         // BFHIP_RT_OVERLAP: copies of neighbouring periods run on the copy engines beside compute
         hipStream_t s_h2d = nullptr, s_d2h = nullptr;
         hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_cmp[2] = {nullptr, nullptr};
@@ -3682,7 +3688,31 @@ int bfhip_engine_rt_wait(bfhip_engine *e, void *rawout, bfhip_overflow overflow[
     }
     rt.waited++;
     if (rawout && rawout != rt.h_out[p]) copy_owned(e, rawout, rt.h_out[p]);      // (a sharded engine: its own samples only)
-    if (overflow) copy_owned_overflow(e, overflow, rt.h_over[p]);
+    if (overflow) {
+        // The reference reads icomm->overflow[ch] at every block and writes it back (bfrun.c:1929-1936),
+        // so a reset by another process (bf_reset_peak: the CLI's peak reset) is picked up by the next
+        // block.  Here the structs live on the device between periods: an entry the HOST changed since
+        // this engine last wrote it becomes the device's state (queued behind whatever is in flight),
+        // and the host's value stands until a period that started after the change reports.
+        const int O = e->n_ch[1];
+        const DevOverflow *dev = rt.h_over[p];
+        const unsigned long long period = rt.waited - 1;                 // the period this call collected
+        if ((int)rt.last_over.size() != O) { rt.last_over.assign(O, DevOverflow()); rt.over_from.assign(O, 0ull); rt.last_valid = false; }
+        for (int o = 0; o < O; o++) {
+            if (e->sharded && !e->out_active[o]) continue;
+            DevOverflow &seen = rt.last_over[o];
+            if (rt.last_valid && memcmp(&overflow[o], &seen, sizeof(DevOverflow)) != 0) {
+                HIPCHK(hipMemcpyAsync(&e->d_over[o], &overflow[o], sizeof(DevOverflow), hipMemcpyHostToDevice, e->stream));
+                memcpy(&seen, &overflow[o], sizeof(DevOverflow));
+                rt.over_from[o] = rt.submitted;                           // periods submitted from now on count on the new state
+                continue;
+            }
+            if (period < rt.over_from[o]) continue;                       // still a period from before the host's change
+            memcpy(&overflow[o], &dev[o], sizeof(DevOverflow));
+            memcpy(&seen, &dev[o], sizeof(DevOverflow));
+        }
+        rt.last_valid = true;
+    }
     return rt.h_status[p][0];
 }
 

@@ -170,3 +170,48 @@ def test_virtual_channels_fall_back_to_plain_launches(hip):
         sb, rb = b.rt_block(blk)
         assert sa == sb and np.array_equal(ra, rb), k
     assert b.rt_stats()["graph"] == 0
+
+
+@pytest.mark.parametrize("flags", [0, 2])
+def test_peak_reset_by_the_host_reaches_the_device(hip, flags):
+    """The reference reads icomm->overflow[ch] before every block and writes it back afterwards
+    (bfrun.c:1929-1936): when another process resets the peaks (bf_reset_peak, the CLI's `upk`), the
+    next block counts on from the reset values.  In real-time mode the structs live on the device
+    between periods: bfhip_engine_rt_wait notices an entry the host changed since the engine last wrote
+    it and makes it the device's state.  Same periods through bfhip_engine_block (which uploads the
+    host's array with every call) must leave the same array after every period."""
+    L, N, I, O = 256, 2, 2, 3
+    coeffs = [(_ir(40 + k, L * N, I) * 30.0, 1.0, 0) for k in range(I * O)]      # loud: the 16-bit outputs clip now and then
+    filters = [dict(in_ch=[i], out_ch=[o], coeff=o * I + i) for o in range(O) for i in range(I)]
+    spec = _spec(L, N, 4, I, O, filters, coeffs, infmt="S24_4LE", outfmt="S16_LE")
+    a, b = cases.build(hip.Engine, spec), cases.build(hip.Engine, spec)
+    b.rt_begin(flags)
+    oa, ob = (hip.Overflow * O)(), (hip.Overflow * O)()
+    for ch in range(O):
+        oa[ch] = a.overflow(ch)
+        ob[ch] = b.overflow(ch)
+    counted = False
+    for k, blk in enumerate(cases.raw_blocks(9, 14, L, I, "S24_4LE", amplitude=0.9)):
+        if k in (5, 9):                                  # "upk": counters and peaks back to zero, max stays
+            for arr in (oa, ob):
+                for ch in range(O):
+                    if k == 9 and ch == 1:
+                        continue                         # ... of some channels only
+                    arr[ch].n_overflows, arr[ch].intlargest, arr[ch].largest = 0, 0, 0.0
+        sa, ra = a.block(blk, overflow=oa)
+        sb, rb = b.rt_block(blk, overflow=ob)
+        assert sa == sb and np.array_equal(ra, rb), k
+        for ch in range(O):
+            got = (ob[ch].n_overflows, ob[ch].intlargest, ob[ch].largest, ob[ch].max)
+            want = (oa[ch].n_overflows, oa[ch].intlargest, oa[ch].largest, oa[ch].max)
+            if k in (5, 9) and not (k == 9 and ch == 1):
+                # the period of the reset itself: the reference (and bfhip_engine_block) count this
+                # block on top of the reset; the real-time path leaves the host's reset standing for
+                # this one period and counts from the next
+                assert got[:3] == (0, 0, 0.0), (k, ch, got)
+                oa[ch].n_overflows, oa[ch].intlargest, oa[ch].largest = 0, 0, 0.0
+                continue
+            assert got == want, (k, ch, got, want)
+            counted = counted or got[0] > 0
+    assert counted
+    b.rt_end()

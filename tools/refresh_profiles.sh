@@ -25,6 +25,12 @@ run configF python bench.py --workload F
 for w in B D E C2 C4 C8; do run config$w python bench.py --workload $w --no-cpu-baseline; done
 run configC_hostio python bench.py --host-io --no-cpu-baseline
 for n in 2 4 8; do BFHIP_BENCH_REHEARSE_RANKS=$n run configC_rank0of${n}_rehearsal python bench.py --no-cpu-baseline; done
+# the reference's own process rule as the multi-GPU split: rank r owns O/N outputs, no collective
+for n in 2 4 8; do BFHIP_BENCH_REHEARSE_RANKS=$n run configC_rank0of${n}_output_sharded_rehearsal python bench.py --shard output --no-cpu-baseline; done
+BFHIP_DIST_BACKEND=gloo run configC_2rank_output_sharded_gloo python bench.py --gpus 2 --shard output --steps 40 --warmup 10 --no-cpu-baseline
+# informative: two blocks per pass over the coefficients (bfhip_engine_block_pair_dev)
+run configC_pairs_informative python bench.py --pairs --no-cpu-baseline
+run configF_pairs_informative python bench.py --pairs --workload F --no-cpu-baseline
 BFHIP_BENCH_REHEARSE_RANKS=8 BFHIP_BENCH_REHEARSE_RCCL=1 run configC_rank0of8_rccl_one_rank python bench.py --no-cpu-baseline
 BFHIP_BENCH_REHEARSE_RANKS=8 BFHIP_BENCH_REHEARSE_RCCL=1 run configD_rank0of8_rccl_one_rank python bench.py --workload D --no-cpu-baseline
 BFHIP_DIST_BACKEND=gloo run configC_2rank_gloo_rehearsal python bench.py --gpus 2 --steps 40 --warmup 10 --no-cpu-baseline
