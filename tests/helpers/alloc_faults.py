@@ -25,6 +25,9 @@ L, N = 256, 3
 rs = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 big = len(sys.argv) > 2 and sys.argv[2] == "big"      # partition length above the LDS limit
 nupc = len(sys.argv) > 2 and sys.argv[2] == "nupc"    # bfhip_nupc instead of a plain engine
+shard = len(sys.argv) > 2 and sys.argv[2] == "shard"  # a shard of a configuration: lazy sets, wide I/O, pairs, one-to-one MAC
+if shard:
+    os.environ["BFHIP_WIDE_IO"] = "1"
 if big:
     L = 16384
 dt = np.float32 if rs == 4 else np.float64
@@ -54,9 +57,65 @@ def nupc_life(stage):
         n.close()
 
 
+def shard_life(stage):
+    """what round 3 added: an engine that runs a shard (lazily registered sets that reach the device
+    inside build_plan, owned-output staging), the planar copies of BFHIP_WIDE_IO, block pairs (a
+    second partial-sum buffer), and a one-to-one plan (mac_diag_kernel's job table)"""
+    I, O = 2, 4
+    whole = bf.Engine(L, N, rs, I, O)
+    e = d = None
+    try:
+        stage[0] = "setup"
+        for eng in (whole,):
+            eng.set_interleaved(0, "S24_4LE")
+            eng.set_interleaved(1, "S24_4LE")
+        cs = [whole.add_coeff(t) for t in taps]
+        whole.add_filter(in_ch=[0], out_ch=[0], coeff=cs[0])
+        whole.finalize()
+        host = [np.ascontiguousarray(whole.read_coeff_processed(c, N)) for c in cs]
+        stage[0] = "shard"
+        e = bf.Engine(L, N, rs, I, O)
+        e.set_interleaved(0, "S24_4LE")
+        e.set_interleaved(1, "S24_4LE")
+        e.enable_pairs(True)
+        for h in host:
+            e.add_coeff_processed_blocks([h[b].ctypes.data for b in range(N)], lazy=True)
+        for o in range(O):
+            for i in range(I):
+                f = e.add_filter(in_ch=[i], out_ch=[o], coeff=(o + i) % 2)
+                e.set_filter_active(f, o < 2)
+        stage[0] = "finalize"
+        e.finalize()
+        stage[0] = "blocks"
+        xs = (rng.standard_normal((L, I)) * 2e5).astype(np.int32)
+        out = np.zeros(L * O * 4, np.uint8)
+        for _ in range(N + 1):
+            e.block(xs, out=out)
+        stage[0] = "switch"
+        e.set_coeff(0, 2)                   # a set this engine never needed: loaded inside build_plan
+        e.block(xs, out=out)
+        stage[0] = "diag"
+        d = bf.Engine(L, N, rs, 3, 3)
+        d.set_interleaved(0, "S24_4LE")
+        d.set_interleaved(1, "FLOAT_LE" if rs == 4 else "FLOAT64_LE")
+        for c in range(3):
+            d.add_filter(in_ch=[c], out_ch=[c], coeff=d.add_coeff(taps[c]))
+        d.finalize()
+        assert d.uses_diag_mac
+        d.block((rng.standard_normal((L, 3)) * 2e5).astype(np.int32))
+        stage[0] = "done"
+    finally:
+        left[0] = bf.lib().bfhip_selftest_fail_alloc(0)
+        for eng in (whole, e, d):
+            if eng is not None:
+                eng.close()
+
+
 def life(stage):
     if nupc:
         return nupc_life(stage)
+    if shard:
+        return shard_life(stage)
     e = bf.Engine(L, N, rs, 3, 3)
     try:
         stage[0] = "setup"

@@ -308,34 +308,39 @@ bfhip_period(struct bffilter_control icomm_fctrl[],
              void *inbuf,
              void *outbuf)
 {
-    static struct bffilter_control other;
+    static struct bffilter_control others[BF_MAXFILTERS];
     struct bffilter_control *fc;
     struct bffilter *flt;
     int n, i, idx, coeff, st;
 
+    if (bfconf->n_processes > 1) {
+        /* the other processes' filters: one pass under the mutex */
+        icomm_mutex(1);
+        for (n = 0; n < BF_MAXFILTERS; n++) {
+            if (bfhip_index[n] < 0 || bfhip_local[n] >= 0) {
+                continue;
+            }
+            flt = bfhip_filter[n];
+            others[n].coeff = icomm->fctrl[n].coeff;
+            others[n].delayblocks = icomm->fctrl[n].delayblocks;
+            for (i = 0; i < flt->n_channels[IN]; i++) {
+                others[n].scale[IN][i] = icomm->fctrl[n].scale[IN][i];
+            }
+            for (i = 0; i < flt->n_channels[OUT]; i++) {
+                others[n].scale[OUT][i] = icomm->fctrl[n].scale[OUT][i];
+            }
+            for (i = 0; i < flt->n_filters[IN]; i++) {
+                others[n].fscale[i] = icomm->fctrl[n].fscale[i];
+            }
+        }
+        icomm_mutex(0);
+    }
     for (n = 0; n < BF_MAXFILTERS; n++) {
         if ((idx = bfhip_index[n]) < 0) {
             continue;
         }
         flt = bfhip_filter[n];
-        if (bfhip_local[n] >= 0) {
-            fc = &icomm_fctrl[bfhip_local[n]];
-        } else {
-            icomm_mutex(1);
-            other.coeff = icomm->fctrl[n].coeff;
-            other.delayblocks = icomm->fctrl[n].delayblocks;
-            for (i = 0; i < flt->n_channels[IN]; i++) {
-                other.scale[IN][i] = icomm->fctrl[n].scale[IN][i];
-            }
-            for (i = 0; i < flt->n_channels[OUT]; i++) {
-                other.scale[OUT][i] = icomm->fctrl[n].scale[OUT][i];
-            }
-            for (i = 0; i < flt->n_filters[IN]; i++) {
-                other.fscale[i] = icomm->fctrl[n].fscale[i];
-            }
-            icomm_mutex(0);
-            fc = &other;
-        }
+        fc = bfhip_local[n] >= 0 ? &icomm_fctrl[bfhip_local[n]] : &others[n];
         coeff = fc->coeff;
         if (events.n_coeff_final == 1) {
             events.coeff_final[0](n, &coeff);
