@@ -747,6 +747,7 @@ void launch_mac(bfhip_engine *e, void *Zp, hipError_t *err) {
             tsplit = 1;
             while (tsplit * 2 <= std::min(all_tiles, atoi(env))) tsplit *= 2;
         }
+        while (all_tiles / tsplit > 16) tsplit *= 2;            // float64 at L = 8192: 32 tiles, 16 per workgroup
         const int tiles = all_tiles / tsplit;
 #define BFHIP_LAUNCH_DIAG(NTFLAG, TL)                                                                                  \
         hipLaunchKernelGGL((mac_diag_kernel<T, NTFLAG, TL>), dim3(n_jobs * tsplit), dim3(256), 0, e->ls,               \
@@ -1298,7 +1299,8 @@ int build_plan_t(bfhip_engine *e) {
     // every output fed by one entry.  They get mac_diag_kernel -- a workgroup per (chunk, output)
     // that walks whole spectra -- and their parallelism from splitting the PARTITIONS of every entry
     // into S parts (part c of every entry = chunk c), not from bin tiles.
-    bool diag_plan = !e->big && (e->L + bins_per_wg - 1) / bins_per_wg <= 16;
+    // (a workgroup holds up to 16 tiles of the spectrum in registers, a job is split over up to 8: 128 tiles)
+    bool diag_plan = !e->big && (e->L + bins_per_wg - 1) / bins_per_wg <= 128;
     if (const char *env = getenv("BFHIP_MAC_DIAG")) diag_plan = diag_plan && atoi(env) != 0;
     {
         std::vector<char> fed(e->n_out_padded, 0);

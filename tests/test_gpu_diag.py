@@ -34,10 +34,10 @@ def _one_to_one(cls, L, N, rs, C, seed=3, powersave=0.0, shard=None):
 
 
 @pytest.mark.parametrize("L,N,rs,C,diag", [(256, 5, 4, 11, True), (1024, 3, 8, 9, True), (8192, 4, 4, 20, True),
-                                           (4096, 6, 8, 5, True), (8192, 3, 8, 6, False), (64, 2, 4, 3, True)])
+                                           (4096, 6, 8, 5, True), (8192, 3, 8, 6, True), (64, 2, 4, 3, True)])
 def test_one_to_one_plan_against_oracle(hip, monkeypatch, L, N, rs, C, diag):
     ge = _one_to_one(hip.Engine, L, N, rs, C)
-    assert ge.uses_diag_mac == diag           # float64 at L = 8192: 32 tiles do not fit the registers
+    assert ge.uses_diag_mac == diag           # (float64 at L = 8192: 32 tiles, two workgroups of 16 per job)
     oe = _one_to_one(bo.Engine, L, N, rs, C)
     monkeypatch.setenv("BFHIP_MAC_DIAG", "0")
     xe = _one_to_one(hip.Engine, L, N, rs, C)

@@ -13,8 +13,10 @@ import ctypes as C
 import numpy as np
 import pytest
 
+import bforacle as bo
 import cases
 import test_gpu_fuzz as fuzz
+from test_gpu_boundary import cv  # noqa: F401  (fixture: the host-side convolver_* symbols)
 
 pytestmark = pytest.mark.gpu
 
@@ -326,3 +328,101 @@ def test_shards_in_real_time_mode_and_on_device_buffers(hip):
             s.block_dev(src, dev_out)
             assert s.sync() == 0
         assert np.array_equal(dev_out.cpu().numpy(), want[b]), b
+
+
+def test_lazy_and_watched_set_rewritten_before_its_first_use(hip, cv):
+    """a set in shared memory that a module process rewrites (bflogic_eq through
+    bfaccess->convolver_coeffs2cbuf) while no filter of THIS engine uses it yet: registered lazily
+    and watched, it is loaded with its CURRENT content when a filter first switches to it, and
+    followed from then on"""
+    import mmap
+    from test_gpu_boundary import _render, p
+    L, N, rs = 512, 3, 4
+    assert cv.convolver_init(None, L, rs) == 1
+    rng = np.random.default_rng(4)
+    first = cases.make_ir(rng, L * N, 1).astype(np.float32)
+    newer = cases.make_ir(rng, L * N, 1).astype(np.float32)
+    later = cases.make_ir(rng, L, 1).astype(np.float32)
+    shm = mmap.mmap(-1, N * 2 * L * rs)
+    base = np.frombuffer(shm, np.float32)
+    addr = [base[b * 2 * L:].ctypes.data for b in range(N)]
+    for b in range(N):
+        _render(cv, first[b * L:(b + 1) * L], L, rs, addr[b])
+
+    def build(mod):
+        e = mod.Engine(L, N, rs, 1, 2)
+        e.set_interleaved(0, "S24_4LE")
+        e.set_interleaved(1, "FLOAT_LE")
+        c0 = e.add_coeff(first)
+        if mod is hip:
+            c1 = e.add_coeff_processed_blocks(addr, watch=True, lazy=True)
+        else:
+            c1 = e.add_coeff(first)
+        e.add_filter(in_ch=[0], out_ch=[0], coeff=c0)
+        e.add_filter(in_ch=[0], out_ch=[1], coeff=c0)
+        if mod is hip:
+            e.set_filter_active(1, False)               # output 1 belongs to another engine
+            e.finalize()
+        return e, c1
+    ge, g1 = build(hip)
+    oe, _ = build(bo)
+    o_newer = oe.add_coeff(newer)
+    mixed = newer.copy()
+    mixed[L:2 * L] = later
+    o_mixed = oe.add_coeff(mixed)
+    assert not ge.coeff_is_resident(g1)
+    for k, blk in enumerate(cases.raw_blocks(2, 3 * N + 2, L, 1, "S24_4LE")):
+        if k == 2:                                      # the "module" renders a whole new response; nobody uses the set yet
+            for b in range(N):
+                cv.convolver_runtime_coeffs2cbuf(p(np.ascontiguousarray(newer[b * L:(b + 1) * L])), C.c_void_p(addr[b]))
+        if k == 4:
+            assert not ge.coeff_is_resident(g1)
+            ge.set_coeff(0, g1)
+            oe.set_coeff(0, o_newer)
+        if k == 2 * N:                                  # ... and one partition again while it is in use
+            cv.convolver_runtime_coeffs2cbuf(p(np.ascontiguousarray(later)), C.c_void_p(addr[1]))
+            oe.set_coeff(0, o_mixed)
+        st, g = ge.block(blk)
+        _, o = oe.block(blk)
+        assert st == 0
+        got = np.frombuffer(g.tobytes(), np.float32).reshape(L, 2)[:, 0]
+        want = np.frombuffer(o.tobytes(), np.float32).reshape(L, 2)[:, 0]
+        assert cases.rel_rms(got, want) <= 1e-5, k
+    assert ge.coeff_is_resident(g1)
+
+
+def test_block_pairs_in_a_shard_that_owns_whole_output_groups(hip):
+    """two blocks per pass over the coefficients in an engine that runs a shard: owning whole groups
+    of eight outputs keeps the plan a uniform crossbar, so the paired kernel runs; the shared buffers
+    end up bit-identical to one engine's single blocks"""
+    import torch
+    dev = torch.device("cuda", 0)
+    L, N, I, O = 1024, 3, 4, 16
+    rng = np.random.default_rng(12)
+    taps = [cases.make_ir(rng, L * N, I).astype(np.float32) for _ in range(I * O)]
+
+    def build(k):
+        e = hip.Engine(L, N, 4, I, O)
+        e.set_interleaved(0, "S24_4LE")
+        e.set_interleaved(1, "S24_4LE")
+        if k is not None:
+            e.enable_pairs(True)
+        for o in range(O):
+            for i in range(I):
+                f = e.add_filter(in_ch=[i], out_ch=[o], coeff=e.add_coeff(taps[o * I + i]))
+                if k is not None:
+                    e.set_filter_active(f, (o // 8) == k)
+        e.finalize()
+        return e
+    whole, shards = build(None), [build(0), build(1)]
+    blocks = cases.raw_blocks(4, 2 * N + 6, L, I, "S24_4LE")
+    srcs = [torch.from_numpy(b).to(dev) for b in blocks]
+    outs = [torch.full((L, O), 0x33333333, dtype=torch.int32, device=dev) for _ in blocks]
+    for k in range(0, len(blocks), 2):
+        for s in shards:
+            s.block_pair_dev(srcs[k], outs[k], srcs[k + 1], outs[k + 1])
+    for s in shards:
+        assert s.sync() == 0 and s.pair_launches > 0
+    for k, blk in enumerate(blocks):
+        _, w = whole.block(blk)
+        assert np.array_equal(outs[k].cpu().numpy().view(np.uint8).ravel(), w), k
