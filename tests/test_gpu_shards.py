@@ -82,7 +82,7 @@ def _same_overflow(a, b, n):
             assert getattr(a[ch], fld) == getattr(b[ch], fld), (ch, fld, getattr(a[ch], fld), getattr(b[ch], fld))
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("BFHIP_SHARD_SEEDS", "40"))))
 def test_shards_write_what_the_whole_engine_writes_bit_for_bit(hip, seed):
     spec, n_blocks, events = fuzz._network(seed)
     rng = np.random.default_rng(777 + seed)
