@@ -10,11 +10,16 @@
  * BIT-EXACTLY against the reference's own code compiled into oracle/_ref (see
  * ref_harness.c, tests/test_oracle_vs_ref.py, fixtures tests/golden/ref_ops_*.npz).
  * The FFT (FFTW3 in the reference: third-party, unpinned version, absent from this
- * image, `Makefile:21`) and the filter_process() control flow cannot be built here, so
- * they are "parity unpinned" by reference output: they are pinned by the mathematical
- * definition of FFTW's R2HC/HC2R transforms (checked against numpy.fft), by analytic
- * known-answer tests (dirac, delayed dirac, cascades) and by an independent
- * numpy/scipy linear convolution of the same inputs.
+ * image, `Makefile:21`) cannot be built here, so the transforms are "parity unpinned" by
+ * reference output: they are pinned by the mathematical definition of FFTW's R2HC/HC2R
+ * transforms (checked against numpy.fft), by analytic known-answer tests (dirac, delayed
+ * dirac, cascades) and by an independent numpy/scipy linear convolution of the same inputs.
+ * The filter_process() CONTROL FLOW (ring slots, delay clamp, cblocks, warm-up, coefficient
+ * switch with cross-fade, cascades) is pinned by the reference's own filter_process():
+ * bfrun.c compiled unchanged into oracle/_ref/ref_filter_process over the product's
+ * convolver.h symbols (ref_filter_process_harness.c), whose outputs this restatement has to
+ * match on random networks (tests/test_gpu_refloop.py; needs the GPU, the ops being the
+ * product's).
  *
  * Layouts are the reference's: halfcomplex spectra from the FFT,
  * "4 re / 4 im" reordered spectra in rings / coefficient partitions / filter outputs.

@@ -1,0 +1,356 @@
+/*
+ * TEST INFRASTRUCTURE ONLY -- never linked into or called from the product.
+ *
+ * The reference's OWN filter_process() (bfrun.c:1008-2083: the block loop with its ring-slot
+ * arithmetic, delay clamp, cblocks truncation, warm-up guard, coefficient switch with cross-fade,
+ * filter-to-filter cascades, input / output mixing), compiled UNCHANGED from the source where it
+ * lies under /root/reference (`#include "bfrun.c"` below: the function is static), run as the
+ * reference runs it -- in a forked filter process, woken through its pipes, on shared buffers --
+ * over the PRODUCT's 22 convolver.h symbols (libbfhip.so: the per-block ops on the GPU, the
+ * pre-fork ops on the host).  This is the drop-in itself, unfused: reference host code on top,
+ * product below the convolver.h boundary, nothing in between.
+ *
+ * What it is for: SURVEY 8(a) rows A7, A8, A12 and the flow of A13 had no reference OUTPUT to be
+ * pinned by (no FFTW here -> the reference's own convolver cannot be built; no tests or fixtures in
+ * the reference).  With this binary the reference's control flow produces outputs: the fused
+ * engine (bfhip_engine_block) and the oracle's restatement of filter_process() have to agree with
+ * them on random filter networks with run-time control changes (tests/test_gpu_refloop.py).  A
+ * wrong ring slot, a missed clamp, a fade on the wrong block is a gross error, not a rounding one.
+ * What it does NOT pin: the FFT itself (A2 / A10) -- both sides use this repository's transforms.
+ *
+ * Linked from the reference's own objects: bfrun.c (included here), dai.c, delay.c, firwindow.c,
+ * emalloc.c, shmalloc.c, inout.c -- every undefined symbol of theirs is closed by those files,
+ * libc and libbfhip.so; no placeholder, no stub.  What the harness supplies is DATA: the `bfconf`
+ * structure bfconf.c would fill from a configuration file (its lexer needs flex, absent here), the
+ * dai_buffer_format tables dai_init() would fill from opened devices, and the input / output
+ * process on the other end of the pipes.  Spec file format: tests/test_gpu_refloop.py writes it.
+ *
+ *   ref_filter_process <spec file> <raw output file>
+ */
+#include <sys/mman.h>
+#include <sys/wait.h>
+
+#include "bfrun.c"
+
+struct bfconf *bfconf = NULL;
+
+struct spec_event { int32_t block, kind, filter, index; double value; };
+
+static void
+rd(FILE *f, void *p, size_t n)
+{
+    if (n > 0 && fread(p, 1, n, f) != n) {
+        fprintf(stderr, "ref_filter_process: short spec file\n");
+        exit(2);
+    }
+}
+
+static int32_t
+rd32(FILE *f)
+{
+    int32_t v;
+    rd(f, &v, 4);
+    return v;
+}
+
+static void *
+shared_zero(size_t bytes)
+{
+    void *p = mmap(NULL, bytes ? bytes : 1, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+    if (p == MAP_FAILED) {
+        perror("mmap");
+        exit(2);
+    }
+    memset(p, 0, bytes);
+    return p;
+}
+
+/* the formats a spec may name: code -> (isfloat, bytes, sbytes) as bfconf.c:358-533 tabulates them */
+static void
+set_format(struct sample_format *sf, int code)
+{
+    static const int tab[][3] = { {0, 2, 2}, {0, 4, 3}, {0, 4, 4}, {1, 4, 4}, {1, 8, 8}, {0, 3, 3} };   /* S16 S24_4 S32 F32 F64 S24 (LE) */
+    memset(sf, 0, sizeof(*sf));
+    sf->isfloat = tab[code][0];
+    sf->bytes = tab[code][1];
+    sf->sbytes = tab[code][2];
+    sf->swap = false;
+    sf->scale = sf->isfloat ? 1.0 : 1.0 / (double)((uint64_t)1 << ((sf->sbytes << 3) - 1));
+}
+
+int
+main(int argc, char *argv[])
+{
+    static struct bfconf conf;
+    FILE *f, *fo;
+    int L, N, rs, n_ch[2], fmt[2], n_coeffs, n_filters, n_blocks, n_events;
+    int n, i, c, k, curbuf = 0, status = 0;
+    int in_pipe[2], out_pipe[2], f2f[1][2], filter_writefd[1];
+    int *all[2];
+    struct spec_event *ev;
+    void *inbuf[2], *outbuf[2], **in_freq, **out_freq;
+    struct bfaccess bfaccess;
+    uint8_t *rawin;
+    size_t in_bytes, out_bytes;
+    char tok = 0;
+    pid_t pid;
+
+    if (argc != 3 || (f = fopen(argv[1], "rb")) == NULL) {
+        fprintf(stderr, "usage: ref_filter_process spec out.raw\n");
+        return 2;
+    }
+    if (rd32(f) != 0x42465250) {
+        fprintf(stderr, "ref_filter_process: bad magic\n");
+        return 2;
+    }
+    L = rd32(f); N = rd32(f); rs = rd32(f);
+    n_ch[IN] = rd32(f); n_ch[OUT] = rd32(f);
+    fmt[IN] = rd32(f); fmt[OUT] = rd32(f);
+    n_coeffs = rd32(f); n_filters = rd32(f); n_blocks = rd32(f); n_events = rd32(f);
+
+    /* ---- what bfconf_init() leaves behind (bfconf.c:2786 ff.), for a configuration without N:1
+       channels, delays, dither or modules */
+    bfconf = &conf;
+    memset(&conf, 0, sizeof(conf));
+    conf.cpu_mhz = 1000.0;
+    conf.n_cpus = 1;
+    conf.sampling_rate = 44100;
+    conf.filter_length = L;
+    conf.n_blocks = N;
+    conf.realsize = rs;
+    conf.blocking_io = true;
+    conf.quiet = true;
+    conf.n_processes = 1;
+    if (!convolver_init(NULL, L, rs)) {
+        return 2;
+    }
+    FOR_IN_AND_OUT {
+        conf.n_channels[IO] = conf.n_physical_channels[IO] = n_ch[IO];
+        conf.n_virtperphys[IO] = emalloc(n_ch[IO] * sizeof(int));
+        conf.phys2virt[IO] = emalloc(n_ch[IO] * sizeof(int *));
+        conf.virt2phys[IO] = emalloc(n_ch[IO] * sizeof(int));
+        conf.delay[IO] = emalloc(n_ch[IO] * sizeof(int));
+        conf.maxdelay[IO] = emalloc(n_ch[IO] * sizeof(int));
+        conf.mute[IO] = emalloc(n_ch[IO] * sizeof(bool_t));
+        conf.subdelay[IO] = emalloc(n_ch[IO] * sizeof(int));
+        all[IO] = emalloc(n_ch[IO] * sizeof(int));
+        for (n = 0; n < n_ch[IO]; n++) {
+            conf.n_virtperphys[IO][n] = 1;
+            conf.phys2virt[IO][n] = emalloc(sizeof(int));
+            conf.phys2virt[IO][n][0] = n;
+            conf.virt2phys[IO][n] = n;
+            conf.delay[IO][n] = conf.maxdelay[IO][n] = 0;
+            conf.mute[IO][n] = false;
+            conf.subdelay[IO][n] = BF_UNDEFINED_SUBDELAY;
+            all[IO][n] = n;
+        }
+        dai_buffer_format[IO] = emalloc(sizeof(struct dai_buffer_format));
+        memset(dai_buffer_format[IO], 0, sizeof(struct dai_buffer_format));
+        dai_buffer_format[IO]->n_samples = L;
+        dai_buffer_format[IO]->n_channels = n_ch[IO];
+        for (n = 0; n < n_ch[IO]; n++) {
+            /* one interleaved device with all channels open (dai.c:537-576) */
+            set_format(&dai_buffer_format[IO]->bf[n].sf, fmt[IO]);
+            dai_buffer_format[IO]->bf[n].sample_spacing = n_ch[IO];
+            dai_buffer_format[IO]->bf[n].byte_offset = n * dai_buffer_format[IO]->bf[n].sf.bytes;
+        }
+        dai_buffer_format[IO]->n_bytes = L * n_ch[IO] * dai_buffer_format[IO]->bf[0].sf.bytes;
+    }
+    conf.dither_state = emalloc(n_ch[OUT] * sizeof(struct dither_state *));
+    memset(conf.dither_state, 0, n_ch[OUT] * sizeof(struct dither_state *));
+
+    /* coefficient sets the way load_coeff() prepares them (bfconf.c:1979-2019): one
+       convolver_coeffs2cbuf() per block of L taps */
+    conf.n_coeffs = n_coeffs;
+    conf.coeffs = emalloc(n_coeffs * sizeof(struct bfcoeff));
+    conf.coeffs_data = emalloc(n_coeffs * sizeof(void **));
+    memset(conf.coeffs, 0, n_coeffs * sizeof(struct bfcoeff));
+    for (c = 0; c < n_coeffs; c++) {
+        int n_taps = rd32(f), blocks = rd32(f);
+        double scale;
+        uint8_t *taps, *zbuf;
+        rd(f, &scale, 8);
+        taps = emalloc((size_t)n_taps * rs + 1);
+        rd(f, taps, (size_t)n_taps * rs);
+        if (blocks <= 0) {
+            blocks = (n_taps + L - 1) / L;
+        }
+        zbuf = emalloc((size_t)L * rs);
+        memset(zbuf, 0, (size_t)L * rs);
+        conf.coeffs[c].intname = c;
+        conf.coeffs[c].n_blocks = blocks;
+        conf.coeffs_data[c] = emalloc(blocks * sizeof(void *));
+        for (n = 0; n < blocks; n++) {
+            if (n * L > n_taps) {
+                conf.coeffs_data[c][n] = convolver_coeffs2cbuf(zbuf, L, scale, NULL);
+            } else if ((n + 1) * L > n_taps) {
+                conf.coeffs_data[c][n] = convolver_coeffs2cbuf(&taps[(size_t)n * L * rs], n_taps - n * L, scale, NULL);
+            } else {
+                conf.coeffs_data[c][n] = convolver_coeffs2cbuf(&taps[(size_t)n * L * rs], L, scale, NULL);
+            }
+            if (conf.coeffs_data[c][n] == NULL) {
+                fprintf(stderr, "ref_filter_process: coefficient set %d rejected\n", c);
+                return 2;
+            }
+        }
+    }
+
+    /* filters, already in evaluation order (bfconf.c:2933-2964 sorts them so) */
+    conf.n_filters = n_filters;
+    conf.filters = emalloc(n_filters * sizeof(struct bffilter));
+    conf.initfctrl = emalloc(n_filters * sizeof(struct bffilter_control));
+    memset(conf.filters, 0, n_filters * sizeof(struct bffilter));
+    memset(conf.initfctrl, 0, n_filters * sizeof(struct bffilter_control));
+    for (n = 0; n < n_filters; n++) {
+        struct bffilter *fl = &conf.filters[n];
+        struct bffilter_control *fc = &conf.initfctrl[n];
+        fl->intname = n;
+        fl->n_channels[IN] = rd32(f);
+        fl->n_filters[IN] = rd32(f);
+        fl->n_channels[OUT] = rd32(f);
+        fc->coeff = rd32(f);
+        fc->delayblocks = rd32(f);
+        fl->crossfade = rd32(f);
+        fl->channels[IN] = emalloc((fl->n_channels[IN] + 1) * sizeof(int));
+        fl->filters[IN] = emalloc((fl->n_filters[IN] + 1) * sizeof(int));
+        fl->channels[OUT] = emalloc((fl->n_channels[OUT] + 1) * sizeof(int));
+        fl->filters[OUT] = emalloc(sizeof(int));
+        rd(f, fl->channels[IN], fl->n_channels[IN] * 4);
+        rd(f, fc->scale[IN], fl->n_channels[IN] * 8);
+        rd(f, fl->filters[IN], fl->n_filters[IN] * 4);
+        rd(f, fc->fscale, fl->n_filters[IN] * 8);
+        rd(f, fl->channels[OUT], fl->n_channels[OUT] * 4);
+        rd(f, fc->scale[OUT], fl->n_channels[OUT] * 8);
+    }
+    conf.fproc = emalloc(sizeof(struct filter_process));
+    conf.fproc[0].n_filters = n_filters;
+    conf.fproc[0].filters = conf.filters;
+    FOR_IN_AND_OUT {
+        /* the channels the filters of the (one) process touch (bfconf.c:2858-2884) */
+        char used[BF_MAXCHANNELS];
+        memset(used, 0, sizeof(used));
+        for (n = 0; n < n_filters; n++) {
+            for (i = 0; i < conf.filters[n].n_channels[IO]; i++) {
+                used[conf.filters[n].channels[IO][i]] = 1;
+            }
+        }
+        conf.fproc[0].unique_channels[IO] = emalloc(n_ch[IO] * sizeof(int));
+        conf.fproc[0].n_unique_channels[IO] = 0;
+        for (n = 0; n < n_ch[IO]; n++) {
+            if (used[n]) {
+                conf.fproc[0].unique_channels[IO][conf.fproc[0].n_unique_channels[IO]++] = n;
+            }
+        }
+    }
+    ev = emalloc((n_events + 1) * sizeof(struct spec_event));
+    rd(f, ev, n_events * sizeof(struct spec_event));
+    in_bytes = dai_buffer_format[IN]->n_bytes;
+    out_bytes = dai_buffer_format[OUT]->n_bytes;
+    rawin = emalloc((size_t)n_blocks * in_bytes + 1);
+    rd(f, rawin, (size_t)n_blocks * in_bytes);
+    fclose(f);
+
+    /* ---- what bfrun() sets up before it forks (bfrun.c:2160-2310) */
+    icomm = shared_zero(sizeof(struct intercomm_area));
+    for (n = 0; n < n_filters; n++) {
+        icomm->fctrl[n] = conf.initfctrl[n];
+    }
+    icomm->n_pids = 0;
+    icomm->exit_status = BF_EXIT_OK;
+    for (n = 0; n < n_ch[OUT]; n++) {
+        struct sample_format *sf = &dai_buffer_format[OUT]->bf[n].sf;
+        icomm->overflow[n].max = sf->isfloat ? 1.0 : (double)((uint64_t)1 << ((sf->sbytes << 3) - 1)) - 1;
+    }
+    if (pipe(mutex_pipe) == -1 || pipe(in_pipe) == -1 || pipe(out_pipe) == -1 || pipe(f2f[0]) == -1 ||
+        !writefd(mutex_pipe[1], &tok, 1))
+    {
+        perror("pipe");
+        return 2;
+    }
+    init_events();
+    memset(&bfaccess, 0, sizeof(bfaccess));
+    bfaccess.fctrl = icomm->fctrl;
+    bfaccess.overflow = icomm->overflow;
+    bfaccess.realsize = rs;
+    bfaccess.coeffs_data = conf.coeffs_data;
+    bfaccess.control_mutex = icomm_mutex;
+    for (k = 0; k < 2; k++) {
+        inbuf[k] = shared_zero(in_bytes);
+        outbuf[k] = shared_zero(out_bytes);
+    }
+    in_freq = emalloc(n_ch[IN] * sizeof(void *));
+    out_freq = emalloc(n_ch[OUT] * sizeof(void *));
+    for (n = 0; n < n_ch[IN]; n++) {
+        in_freq[n] = shared_zero(convolver_cbufsize());
+    }
+    for (n = 0; n < n_ch[OUT]; n++) {
+        out_freq[n] = shared_zero(convolver_cbufsize());
+    }
+    filter_writefd[0] = -1;
+
+    switch (pid = fork()) {
+    case -1:
+        perror("fork");
+        return 2;
+    case 0:
+        /* ---- the filter process (bfrun.c:2329-2375) */
+        close(in_pipe[1]);
+        close(out_pipe[0]);
+        filter_process(&bfaccess, inbuf, outbuf, in_freq, out_freq,
+                       f2f[0][0], filter_writefd,
+                       in_pipe[0], -1, out_pipe[1], -1,
+                       n_ch[IN], all[IN], n_ch[OUT], all[OUT],
+                       conf.fproc[0].n_unique_channels[IN], conf.fproc[0].unique_channels[IN],
+                       conf.fproc[0].n_unique_channels[OUT], conf.fproc[0].unique_channels[OUT],
+                       n_filters, conf.filters, 0,
+                       true, true, false, false);
+        _exit(3);       /* never reached */
+    default:
+        break;
+    }
+    close(in_pipe[0]);
+    close(out_pipe[1]);
+
+    /* ---- the input and output processes on the other end of the pipes (bfrun.c:2480-2616) */
+    if ((fo = fopen(argv[2], "wb")) == NULL) {
+        perror(argv[2]);
+        return 2;
+    }
+    if (!writefd(in_pipe[1], &tok, 1) || !readfd(out_pipe[0], &tok, 1)) {       /* the init handshake */
+        fprintf(stderr, "ref_filter_process: the filter process did not come up\n");
+        return 1;
+    }
+    for (k = 0; k < n_blocks; k++) {
+        for (i = 0; i < n_events; i++) {
+            if (ev[i].block != k) {
+                continue;
+            }
+            icomm_mutex(1);             /* what bflogic_cli does through bfaccess->control_mutex */
+            switch (ev[i].kind) {
+            case 0: icomm->fctrl[ev[i].filter].coeff = (int)ev[i].value; break;
+            case 1: icomm->fctrl[ev[i].filter].scale[IN][ev[i].index] = ev[i].value; break;
+            case 2: icomm->fctrl[ev[i].filter].scale[OUT][ev[i].index] = ev[i].value; break;
+            case 3: icomm->fctrl[ev[i].filter].fscale[ev[i].index] = ev[i].value; break;
+            default: icomm->fctrl[ev[i].filter].delayblocks = (int)ev[i].value; break;
+            }
+            icomm_mutex(0);
+        }
+        memcpy(inbuf[curbuf], rawin + (size_t)k * in_bytes, in_bytes);
+        if (!writefd(in_pipe[1], &tok, 1) || !readfd(out_pipe[0], &tok, 1)) {
+            fprintf(stderr, "ref_filter_process: the filter process died in block %d\n", k);
+            return 1;
+        }
+        fwrite(outbuf[curbuf], 1, out_bytes, fo);
+        curbuf = !curbuf;
+    }
+    fclose(fo);
+    for (n = 0; n < n_ch[OUT]; n++) {
+        printf("output %d: %u overflows, intlargest %d, largest %.17g\n", n, icomm->overflow[n].n_overflows,
+               (int)icomm->overflow[n].intlargest, icomm->overflow[n].largest);
+    }
+    /* closing the wake pipe ends the filter process the way the reference ends: its read fails and
+       it calls bf_exit() */
+    close(in_pipe[1]);
+    waitpid(pid, &status, 0);
+    return 0;
+}

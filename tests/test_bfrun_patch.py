@@ -96,3 +96,23 @@ def test_every_convolver_symbol_the_host_objects_need_is_exported(tmp_path):
     dyn = subprocess.run(["nm", "-D", "--defined-only", bf.LIB_PATH], capture_output=True, text=True).stdout.split()
     missing = [s for s in need if s not in dyn]
     assert not missing, missing
+
+
+def test_reference_filter_process_binary_is_built_without_placeholders():
+    """oracle/_ref/ref_filter_process -- the reference's own filter_process() (bfrun.c unchanged) over the
+    product's convolver.h symbols, tests/test_gpu_refloop.py's checker -- is (re)built by `make -C oracle
+    ref` from the sources where they lie, linked with -z defs; every undefined symbol it has left is
+    libc's, libm's or libbfhip.so's"""
+    import brutefir_amd as bf
+    assert os.path.exists(bf.LIB_PATH), "build the product first (python -m brutefir_amd.build)"
+    r = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_filter_process")
+    assert os.path.exists(exe)
+    undef = subprocess.run(["nm", "-D", "--undefined-only", exe], capture_output=True, text=True).stdout.split()
+    ours = sorted(s for s in undef if s.startswith(("convolver_", "bfhip_")))
+    assert len(ours) >= 15 and all(s.startswith("convolver_") for s in ours), ours     # the convolver.h boundary, nothing else
+    dyn = subprocess.run(["nm", "-D", "--defined-only", bf.LIB_PATH], capture_output=True, text=True).stdout.split()
+    assert all(s in dyn for s in ours)
+    recipe = open(os.path.join(ROOT, "oracle", "Makefile")).read()
+    assert "defsym" not in recipe.split("$(FPROC):")[1].split("endif")[0]

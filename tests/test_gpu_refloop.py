@@ -1,0 +1,179 @@
+"""GPU: the reference's OWN filter_process() -- bfrun.c compiled unchanged from /root/reference into
+oracle/_ref/ref_filter_process (oracle/ref_filter_process_harness.c; built in the build container, the
+binary travels) -- run as a forked filter process over the PRODUCT's 22 convolver.h symbols
+(libbfhip.so, the unfused path: per-block ops on the GPU), against
+
+  * the fused engine (bfhip_engine_block), and
+  * the oracle's restatement of filter_process(),
+
+on random filter networks with run-time control sequences (tests/test_gpu_fuzz.py's generator:
+channel and filter inputs, cascades through convolve_eval, several outputs per filter, outputs fed
+by several filters, negative / zero scales, coeff -1, short sets, delayblocks beyond N - 1,
+cross-fading switches; fctrl writes between blocks).
+
+What this pins, and did not have a reference OUTPUT to be pinned by before: the block-ring / delay /
+cblocks / warm-up bookkeeping (`(blockcounter + delay) % n_blocks`, the clamp, the
+`procblocks` guard), the coefficient switch with its one-block cross-fade (A7), the cascade (A8), the
+input and output mixes as filter_process() drives them.  A wrong slot or a fade on the wrong block
+is a gross error, not a rounding one.  What it does not pin: the FFT itself -- both sides of the
+convolver.h boundary are this repository's transforms (FFTW is absent)."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import bforacle as bo
+import cases
+import test_gpu_fuzz as fuzz
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "oracle", "_ref", "ref_filter_process")
+FMT_CODE = {"S16_LE": 0, "S24_4LE": 1, "S32_LE": 2, "FLOAT_LE": 3, "FLOAT64_LE": 4, "S24_LE": 5}
+KIND = {"coeff": 0, "scale_in": 1, "scale_out": 2, "fscale": 3, "delay": 4}
+
+
+def _write_spec(path, spec, blocks, events):
+    rs = spec["rs"]
+    dt = np.float32 if rs == 4 else np.float64
+    evs = []
+    for b, lst in sorted(events.items()):
+        for ev in lst:
+            if ev[0] == "coeff":
+                evs.append((b, 0, ev[1], 0, float(ev[2])))
+            elif ev[0] == "scale":
+                evs.append((b, 1 if ev[2] == 0 else 2, ev[1], ev[3], float(ev[4])))
+            elif ev[0] == "fscale":
+                evs.append((b, 3, ev[1], ev[2], float(ev[3])))
+            else:
+                evs.append((b, 4, ev[1], 0, float(ev[2])))
+    with open(path, "wb") as f:
+        f.write(struct.pack("<12i", 0x42465250, spec["L"], spec["N"], rs, spec["n_in"], spec["n_out"],
+                            FMT_CODE[spec["infmt"]], FMT_CODE[spec["outfmt"]], len(spec["coeffs"]),
+                            len(spec["filters"]), len(blocks), len(evs)))
+        for taps, scale, nb in spec["coeffs"]:
+            t = np.ascontiguousarray(taps, dt)
+            f.write(struct.pack("<iid", len(t), nb, scale))
+            f.write(t.tobytes())
+        for fl in spec["filters"]:
+            f.write(struct.pack("<6i", len(fl["in_ch"]), len(fl["in_f"]), len(fl["out_ch"]), fl["coeff"],
+                                fl["delayblocks"], int(fl["crossfade"])))
+            f.write(np.asarray(fl["in_ch"], np.int32).tobytes())
+            f.write(np.asarray(fl["in_scale"], np.float64).tobytes())
+            f.write(np.asarray(fl["in_f"], np.int32).tobytes())
+            f.write(np.asarray(fl["in_fscale"], np.float64).tobytes())
+            f.write(np.asarray(fl["out_ch"], np.int32).tobytes())
+            f.write(np.asarray(fl["out_scale"], np.float64).tobytes())
+        for ev in evs:
+            f.write(struct.pack("<4id", *ev))
+        for blk in blocks:
+            f.write(np.ascontiguousarray(blk).tobytes())
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BFHIP_REFLOOP_SEEDS", "24"))))
+def test_reference_filter_process_over_the_product_vs_fused_engine_and_oracle(hip, tmp_path, seed):
+    if not os.path.exists(EXE):
+        pytest.fail("oracle/_ref/ref_filter_process is missing: it is built from the reference's bfrun.c in the build "
+                    "container (make -C oracle ref, __graft_entry__.build) and travels to the GPU box")
+    spec, n_blocks, events = fuzz._network(seed + 7000)
+    blocks = cases.raw_blocks(seed, n_blocks, spec["L"], spec["n_in"], spec["infmt"], amplitude=0.2)
+    _write_spec(tmp_path / "spec.bin", spec, blocks, events)
+    r = subprocess.run([EXE, str(tmp_path / "spec.bin"), str(tmp_path / "out.raw")], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-1500:])
+    odt = np.float32 if spec["rs"] == 4 else np.float64
+    ref = np.fromfile(tmp_path / "out.raw", odt).reshape(n_blocks, spec["L"], spec["n_out"]).astype(np.float64)
+    ge, oe = cases.build(hip.Engine, spec), cases.build(bo.Engine, spec)
+    tol = 3e-5 if spec["rs"] == 4 else 1e-11
+    scale = 0.0
+    for b, blk in enumerate(blocks):
+        fuzz._apply(ge, events.get(b, []))
+        fuzz._apply(oe, events.get(b, []))
+        gs, g = ge.block(blk)
+        os_, o = oe.block(blk)
+        assert gs == os_ == 0, (seed, b)
+        gsamp = cases.samples(g, spec["outfmt"]).reshape(spec["L"], spec["n_out"])
+        osamp = cases.samples(o, spec["outfmt"]).reshape(spec["L"], spec["n_out"])
+        scale = max(scale, float(np.abs(ref[b]).max()))
+        for ch in range(spec["n_out"]):
+            want = ref[b][:, ch]
+            lvl = max(float(np.sqrt((want ** 2).mean())), 1e-3 * scale, fuzz.FLOOR)
+            for who, got in (("fused engine", gsamp[:, ch]), ("oracle", osamp[:, ch])):
+                err = float(np.sqrt(((got - want) ** 2).mean()))
+                assert err <= tol * lvl, (who, seed, b, ch, err, lvl, spec["filters"], events)
+    # the overflow structs the reference's loop kept in icomm against the engine's
+    for ln in r.stdout.splitlines():
+        if ln.startswith("output "):
+            ch = int(ln.split()[1].rstrip(":"))
+            assert int(ln.split()[2]) == ge.overflow(ch).n_overflows, ln
+
+
+def _named_specs():
+    """configurations the reference ships, within what the harness sets up (one interleaved device per
+    side, no N:1 channels, no dither): bench1_config's cascade, bench5_config's cli script, and
+    bench4_config's ring of 13 partitions with its delays -- plus a 16-bit output driven into clipping"""
+    rng = np.random.default_rng(99)
+    dirac = np.array([1.0], np.float32)
+    out = {}
+    # bench1_config: two inputs -> four input filters -> two output filters (from_filters), dirac coefficients
+    out["bench1"] = (dict(L=8192, N=8, rs=4, n_in=2, n_out=2, infmt="S24_4LE", outfmt="S24_4LE",
+                          coeffs=[(dirac, 1.0, 0)] * 6,
+                          filters=[_f(in_ch=[0], coeff=2), _f(in_ch=[0], coeff=3), _f(in_ch=[1], coeff=4), _f(in_ch=[1], coeff=5),
+                                   _f(in_f=[0, 3], out_ch=[0], coeff=0), _f(in_f=[1, 2], out_ch=[1], coeff=1)]), 10, {}, 4.0)
+    # bench5_config: 26 cross-fading one-to-one filters toggled between coefficient 0 and the dirac (-1) every block
+    ev = {b: [("coeff", f, 0 if b % 2 == 0 else -1) for f in range(26)] for b in range(1, 7)}
+    out["bench5"] = (dict(L=8192, N=8, rs=4, n_in=26, n_out=26, infmt="S24_4LE", outfmt="S24_4LE",
+                          coeffs=[(cases.make_ir(rng, 8192 * 3, 1), 1.0, 0)],
+                          filters=[_f(in_ch=[i], out_ch=[i], coeff=0, crossfade=True) for i in range(26)]), 7, ev, 4.0)   # (a fade block: three more float32 round trips)
+    # bench4_config's partitioning: 4096 x 13 (a ring that is no power of two), delays up to and beyond N - 1
+    flt = [_f(in_ch=[i], out_ch=[o], coeff=(o + i) % 3, delayblocks=[0, 1, 5, 12, 40][(o * 3 + i) % 5],
+              in_scale=[[1.0, -0.5, 0.25][(o + i) % 3]]) for o in range(4) for i in range(3)]
+    ev = {14: [("delay", 2, 7), ("coeff", 5, 1)], 20: [("delay", 2, 0), ("scale", 7, 0, 0, 2.0)], 30: [("coeff", 5, -1)]}
+    out["ring13"] = (dict(L=4096, N=13, rs=8, n_in=3, n_out=4, infmt="S24_4LE", outfmt="FLOAT64_LE",
+                          coeffs=[(cases.make_ir(rng, 4096 * 13, 3), 1.0, 0), (cases.make_ir(rng, 4096 * 4 + 100, 3), 0.5, 0),
+                                  (cases.make_ir(rng, 4096 * 13, 3), -1.0, 2)], filters=flt), 2 * 13 + 8, ev, None)
+    # 16-bit output, loud: the clip and the overflow counters of icomm->overflow
+    out["clip16"] = (dict(L=1024, N=4, rs=4, n_in=2, n_out=2, infmt="S24_4LE", outfmt="S16_LE",
+                          coeffs=[(cases.make_ir(rng, 1024 * 4, 1) * 12.0, 1.0, 0)],
+                          filters=[_f(in_ch=[i], out_ch=[o], coeff=0) for o in range(2) for i in range(2)]), 12, {}, 1.0)
+    return out
+
+
+def _f(in_ch=(), in_scale=None, in_f=(), in_fscale=None, out_ch=(), out_scale=None, coeff=-1, delayblocks=0, crossfade=False):
+    return dict(in_ch=list(in_ch), in_scale=list(in_scale) if in_scale else [1.0] * len(in_ch), in_f=list(in_f),
+                in_fscale=list(in_fscale) if in_fscale else [1.0] * len(in_f), out_ch=list(out_ch),
+                out_scale=list(out_scale) if out_scale else [1.0] * len(out_ch), coeff=coeff, delayblocks=delayblocks, crossfade=crossfade)
+
+
+@pytest.mark.parametrize("name", ["bench1", "bench5", "ring13", "clip16"])
+def test_reference_filter_process_on_the_reference_s_own_configurations(hip, tmp_path, name):
+    if not os.path.exists(EXE):
+        pytest.fail("oracle/_ref/ref_filter_process is missing (built from the reference's bfrun.c in the build container)")
+    spec, n_blocks, events, lsb_tol = _named_specs()[name]
+    amp = 0.9 if name == "clip16" else 0.2
+    blocks = cases.raw_blocks(5, n_blocks, spec["L"], spec["n_in"], spec["infmt"], amplitude=amp)
+    _write_spec(tmp_path / "spec.bin", spec, blocks, events)
+    r = subprocess.run([EXE, str(tmp_path / "spec.bin"), str(tmp_path / "out.raw")], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-1500:])
+    odt = {"S24_4LE": np.int32, "S16_LE": np.int16, "FLOAT64_LE": np.float64}[spec["outfmt"]]
+    ref = np.fromfile(tmp_path / "out.raw", odt).reshape(n_blocks, spec["L"], spec["n_out"])
+    ge = cases.build(hip.Engine, spec)
+    for b, blk in enumerate(blocks):
+        fuzz._apply(ge, events.get(b, []))
+        st, g = ge.block(blk)
+        assert st == 0
+        got = np.frombuffer(g.tobytes(), odt).reshape(spec["L"], spec["n_out"])
+        if lsb_tol is None:
+            assert cases.rel_rms(got, ref[b]) <= 1e-11 or np.abs(ref[b]).max() == 0, (name, b)
+        else:
+            assert np.abs(got.astype(np.int64) - ref[b].astype(np.int64)).max() <= lsb_tol, (name, b)
+    counted = 0
+    for ln in r.stdout.splitlines():
+        if ln.startswith("output "):
+            ch, n_over = int(ln.split()[1].rstrip(":")), int(ln.split()[2])
+            mine = ge.overflow(ch).n_overflows
+            counted += n_over
+            # a sample within one count of the clip level may fall on either side of it
+            assert abs(n_over - mine) <= max(2, n_over // 100), (name, ln, mine)
+    assert counted > 0 or name != "clip16"
