@@ -649,7 +649,20 @@ void convolver_cbuf2raw(void *cbuf, void *outbuf, struct bfhip_buffer_format *bf
         });
     }
     int flag = 0;
-    if (!down(hraw, d_raw, span) || !down(overflow, G.d_over, sizeof(DevOverflow)) || !down(&flag, G.d_flag, sizeof(int))) return;
+    /* Only THIS channel's samples may reach the host buffer: with several filter processes the
+       channels of one interleaved frame are converted by different processes at the same time
+       (bfrun.c:1875-2003 behind the second barrier), and writing the whole span back would put a
+       neighbour's stale bytes over what the other process has just written -- found by running the
+       reference's own multi-process filter_process() over these symbols (tests/test_gpu_refloop.py).
+       real2raw writes its own samples only (real2raw.h); so does this. */
+    static thread_local std::vector<uint8_t> stage;
+    stage.resize(span);
+    if (!down(stage.data(), d_raw, span) || !down(overflow, G.d_over, sizeof(DevOverflow)) || !down(&flag, G.d_flag, sizeof(int))) return;
+    {
+        const size_t sb = (size_t)bf->sf.bytes, step = (size_t)bf->sample_spacing * sb;
+        if (step == sb) memcpy(hraw, stage.data(), sb * (size_t)G.L);
+        else for (int n = 0; n < G.L; n++) memcpy(hraw + (size_t)n * step, stage.data() + (size_t)n * step, sb);
+    }
     if (flag) {
         (void)hipMemsetAsync(G.d_flag, 0, sizeof(int), G.stream);
         fatal(2, "NaN or Inf values in the output! Bad output. Aborting.");   /* real2raw.h:27-30 */

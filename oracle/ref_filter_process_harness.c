@@ -83,23 +83,24 @@ main(int argc, char *argv[])
 {
     static struct bfconf conf;
     FILE *f, *fo;
-    int L, N, rs, n_ch[2], fmt[2], n_coeffs, n_filters, n_blocks, n_events;
-    int n, i, c, k, curbuf = 0, status = 0;
-    int in_pipe[2], out_pipe[2], f2f[1][2], filter_writefd[1];
-    int *all[2];
+    int L, N, rs, n_ch[2], fmt[2], n_coeffs, n_filters, n_blocks, n_events, n_procs;
+    int n, i, j, c, k, curbuf = 0, status = 0;
+    int in_pipe[2], out_pipe[2], f2f[BF_MAXPROCESSES][2], filter_writefd[BF_MAXPROCESSES];
+    int *fft_ch[BF_MAXPROCESSES][2], n_fft_ch[BF_MAXPROCESSES][2], cpos[2], *fproc_of;
+    char toks[BF_MAXPROCESSES];
+    pid_t pids[BF_MAXPROCESSES];
     struct spec_event *ev;
     void *inbuf[2], *outbuf[2], **in_freq, **out_freq;
     struct bfaccess bfaccess;
     uint8_t *rawin;
     size_t in_bytes, out_bytes;
     char tok = 0;
-    pid_t pid;
 
     if (argc != 3 || (f = fopen(argv[1], "rb")) == NULL) {
         fprintf(stderr, "usage: ref_filter_process spec out.raw\n");
         return 2;
     }
-    if (rd32(f) != 0x42465250) {
+    if (rd32(f) != 0x42465251) {
         fprintf(stderr, "ref_filter_process: bad magic\n");
         return 2;
     }
@@ -107,6 +108,11 @@ main(int argc, char *argv[])
     n_ch[IN] = rd32(f); n_ch[OUT] = rd32(f);
     fmt[IN] = rd32(f); fmt[OUT] = rd32(f);
     n_coeffs = rd32(f); n_filters = rd32(f); n_blocks = rd32(f); n_events = rd32(f);
+    n_procs = rd32(f);
+    if (n_procs < 1 || n_procs > BF_MAXPROCESSES) {
+        fprintf(stderr, "ref_filter_process: bad process count\n");
+        return 2;
+    }
 
     /* ---- what bfconf_init() leaves behind (bfconf.c:2786 ff.), for a configuration without N:1
        channels, delays, dither or modules */
@@ -120,7 +126,8 @@ main(int argc, char *argv[])
     conf.realsize = rs;
     conf.blocking_io = true;
     conf.quiet = true;
-    conf.n_processes = 1;
+    conf.n_processes = n_procs;
+    conf.benchmark = getenv("BFREF_BENCHMARK") != NULL;     /* `benchmark: true;`: the stage table of bfrun.c:2035-2078 on stderr */
     if (!convolver_init(NULL, L, rs)) {
         return 2;
     }
@@ -133,7 +140,6 @@ main(int argc, char *argv[])
         conf.maxdelay[IO] = emalloc(n_ch[IO] * sizeof(int));
         conf.mute[IO] = emalloc(n_ch[IO] * sizeof(bool_t));
         conf.subdelay[IO] = emalloc(n_ch[IO] * sizeof(int));
-        all[IO] = emalloc(n_ch[IO] * sizeof(int));
         for (n = 0; n < n_ch[IO]; n++) {
             conf.n_virtperphys[IO][n] = 1;
             conf.phys2virt[IO][n] = emalloc(sizeof(int));
@@ -142,7 +148,6 @@ main(int argc, char *argv[])
             conf.delay[IO][n] = conf.maxdelay[IO][n] = 0;
             conf.mute[IO][n] = false;
             conf.subdelay[IO][n] = BF_UNDEFINED_SUBDELAY;
-            all[IO][n] = n;
         }
         dai_buffer_format[IO] = emalloc(sizeof(struct dai_buffer_format));
         memset(dai_buffer_format[IO], 0, sizeof(struct dai_buffer_format));
@@ -201,10 +206,12 @@ main(int argc, char *argv[])
     conf.initfctrl = emalloc(n_filters * sizeof(struct bffilter_control));
     memset(conf.filters, 0, n_filters * sizeof(struct bffilter));
     memset(conf.initfctrl, 0, n_filters * sizeof(struct bffilter_control));
+    fproc_of = emalloc((n_filters + 1) * sizeof(int));
     for (n = 0; n < n_filters; n++) {
         struct bffilter *fl = &conf.filters[n];
         struct bffilter_control *fc = &conf.initfctrl[n];
         fl->intname = n;
+        fproc_of[n] = rd32(f);              /* the process bfconf's load balancing gave the filter to (bfconf.c:2227-2318) */
         fl->n_channels[IN] = rd32(f);
         fl->n_filters[IN] = rd32(f);
         fl->n_channels[OUT] = rd32(f);
@@ -222,24 +229,48 @@ main(int argc, char *argv[])
         rd(f, fl->channels[OUT], fl->n_channels[OUT] * 4);
         rd(f, fc->scale[OUT], fl->n_channels[OUT] * 8);
     }
-    conf.fproc = emalloc(sizeof(struct filter_process));
-    conf.fproc[0].n_filters = n_filters;
-    conf.fproc[0].filters = conf.filters;
-    FOR_IN_AND_OUT {
-        /* the channels the filters of the (one) process touch (bfconf.c:2858-2884) */
-        char used[BF_MAXCHANNELS];
-        memset(used, 0, sizeof(used));
+    conf.fproc = emalloc(n_procs * sizeof(struct filter_process));
+    for (k = 0; k < n_procs; k++) {
+        /* the filters of process k, in evaluation order (bfconf.c:2933-2964), and the channels they
+           touch (bfconf.c:2858-2884) */
+        conf.fproc[k].filters = emalloc((n_filters + 1) * sizeof(struct bffilter));
+        conf.fproc[k].n_filters = 0;
         for (n = 0; n < n_filters; n++) {
-            for (i = 0; i < conf.filters[n].n_channels[IO]; i++) {
-                used[conf.filters[n].channels[IO][i]] = 1;
+            if (fproc_of[n] == k) {
+                conf.fproc[k].filters[conf.fproc[k].n_filters++] = conf.filters[n];
             }
         }
-        conf.fproc[0].unique_channels[IO] = emalloc(n_ch[IO] * sizeof(int));
-        conf.fproc[0].n_unique_channels[IO] = 0;
-        for (n = 0; n < n_ch[IO]; n++) {
-            if (used[n]) {
-                conf.fproc[0].unique_channels[IO][conf.fproc[0].n_unique_channels[IO]++] = n;
+        FOR_IN_AND_OUT {
+            char used[BF_MAXCHANNELS];
+            memset(used, 0, sizeof(used));
+            for (n = 0; n < conf.fproc[k].n_filters; n++) {
+                for (i = 0; i < conf.fproc[k].filters[n].n_channels[IO]; i++) {
+                    used[conf.fproc[k].filters[n].channels[IO][i]] = 1;
+                }
             }
+            conf.fproc[k].unique_channels[IO] = emalloc((n_ch[IO] + 1) * sizeof(int));
+            conf.fproc[k].n_unique_channels[IO] = 0;
+            for (n = 0; n < n_ch[IO]; n++) {
+                if (used[n]) {
+                    conf.fproc[k].unique_channels[IO][conf.fproc[k].n_unique_channels[IO]++] = n;
+                }
+            }
+        }
+    }
+    /* which channels a process transforms / converts: bfrun.c:2312-2328 */
+    cpos[IN] = cpos[OUT] = 0;
+    for (k = 0; k < n_procs; k++) {
+        FOR_IN_AND_OUT {
+            int nc = conf.n_channels[IO] / n_procs;
+            fft_ch[k][IO] = emalloc((n_ch[IO] + 1) * sizeof(int));
+            j = 0;
+            while ((j < nc || k == n_procs - 1) && cpos[IO] < conf.n_physical_channels[IO]) {
+                for (i = 0; i < conf.n_virtperphys[IO][cpos[IO]]; i++, j++) {
+                    fft_ch[k][IO][j] = conf.phys2virt[IO][cpos[IO]][i];
+                }
+                cpos[IO]++;
+            }
+            n_fft_ch[k][IO] = j;
         }
     }
     ev = emalloc((n_events + 1) * sizeof(struct spec_event));
@@ -261,12 +292,17 @@ main(int argc, char *argv[])
         struct sample_format *sf = &dai_buffer_format[OUT]->bf[n].sf;
         icomm->overflow[n].max = sf->isfloat ? 1.0 : (double)((uint64_t)1 << ((sf->sbytes << 3) - 1)) - 1;
     }
-    if (pipe(mutex_pipe) == -1 || pipe(in_pipe) == -1 || pipe(out_pipe) == -1 || pipe(f2f[0]) == -1 ||
-        !writefd(mutex_pipe[1], &tok, 1))
-    {
+    if (pipe(mutex_pipe) == -1 || pipe(in_pipe) == -1 || pipe(out_pipe) == -1 || !writefd(mutex_pipe[1], &tok, 1)) {
         perror("pipe");
         return 2;
     }
+    for (k = 0; k < n_procs; k++) {
+        if (pipe(f2f[k]) == -1) {
+            perror("pipe");
+            return 2;
+        }
+    }
+    memset(toks, 0, sizeof(toks));
     init_events();
     memset(&bfaccess, 0, sizeof(bfaccess));
     bfaccess.fctrl = icomm->fctrl;
@@ -286,27 +322,36 @@ main(int argc, char *argv[])
     for (n = 0; n < n_ch[OUT]; n++) {
         out_freq[n] = shared_zero(convolver_cbufsize());
     }
-    filter_writefd[0] = -1;
-
-    switch (pid = fork()) {
-    case -1:
-        perror("fork");
-        return 2;
-    case 0:
-        /* ---- the filter process (bfrun.c:2329-2375) */
-        close(in_pipe[1]);
-        close(out_pipe[0]);
-        filter_process(&bfaccess, inbuf, outbuf, in_freq, out_freq,
-                       f2f[0][0], filter_writefd,
-                       in_pipe[0], -1, out_pipe[1], -1,
-                       n_ch[IN], all[IN], n_ch[OUT], all[OUT],
-                       conf.fproc[0].n_unique_channels[IN], conf.fproc[0].unique_channels[IN],
-                       conf.fproc[0].n_unique_channels[OUT], conf.fproc[0].unique_channels[OUT],
-                       n_filters, conf.filters, 0,
-                       true, true, false, false);
-        _exit(3);       /* never reached */
-    default:
-        break;
+    for (k = 0; k < n_procs; k++) {
+        switch (pids[k] = fork()) {
+        case -1:
+            perror("fork");
+            return 2;
+        case 0:
+            /* ---- filter process k (bfrun.c:2329-2375) */
+            close(in_pipe[1]);
+            close(out_pipe[0]);
+            for (i = 0; i < n_procs; i++) {
+                if (i == k) {
+                    filter_writefd[i] = -1;
+                    close(f2f[i][1]);
+                } else {
+                    close(f2f[i][0]);
+                    filter_writefd[i] = f2f[i][1];
+                }
+            }
+            filter_process(&bfaccess, inbuf, outbuf, in_freq, out_freq,
+                           f2f[k][0], filter_writefd,
+                           in_pipe[0], -1, out_pipe[1], -1,
+                           n_fft_ch[k][IN], fft_ch[k][IN], n_fft_ch[k][OUT], fft_ch[k][OUT],
+                           conf.fproc[k].n_unique_channels[IN], conf.fproc[k].unique_channels[IN],
+                           conf.fproc[k].n_unique_channels[OUT], conf.fproc[k].unique_channels[OUT],
+                           conf.fproc[k].n_filters, conf.fproc[k].filters, k,
+                           true, true, false, false);
+            _exit(3);       /* never reached */
+        default:
+            break;
+        }
     }
     close(in_pipe[0]);
     close(out_pipe[1]);
@@ -316,7 +361,7 @@ main(int argc, char *argv[])
         perror(argv[2]);
         return 2;
     }
-    if (!writefd(in_pipe[1], &tok, 1) || !readfd(out_pipe[0], &tok, 1)) {       /* the init handshake */
+    if (!writefd(in_pipe[1], toks, n_procs) || !readfd(out_pipe[0], toks, n_procs)) {       /* the init handshake */
         fprintf(stderr, "ref_filter_process: the filter process did not come up\n");
         return 1;
     }
@@ -336,8 +381,8 @@ main(int argc, char *argv[])
             icomm_mutex(0);
         }
         memcpy(inbuf[curbuf], rawin + (size_t)k * in_bytes, in_bytes);
-        if (!writefd(in_pipe[1], &tok, 1) || !readfd(out_pipe[0], &tok, 1)) {
-            fprintf(stderr, "ref_filter_process: the filter process died in block %d\n", k);
+        if (!writefd(in_pipe[1], toks, n_procs) || !readfd(out_pipe[0], toks, n_procs)) {
+            fprintf(stderr, "ref_filter_process: a filter process died in block %d\n", k);
             return 1;
         }
         fwrite(outbuf[curbuf], 1, out_bytes, fo);
@@ -351,6 +396,8 @@ main(int argc, char *argv[])
     /* closing the wake pipe ends the filter process the way the reference ends: its read fails and
        it calls bf_exit() */
     close(in_pipe[1]);
-    waitpid(pid, &status, 0);
+    for (k = 0; k < n_procs; k++) {
+        waitpid(pids[k], &status, 0);
+    }
     return 0;
 }

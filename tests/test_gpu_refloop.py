@@ -31,11 +31,12 @@ import test_gpu_fuzz as fuzz
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "oracle", "_ref", "ref_filter_process")
+EXE_PATCHED = os.path.join(ROOT, "oracle", "_ref", "ref_filter_process_bfhip")
 FMT_CODE = {"S16_LE": 0, "S24_4LE": 1, "S32_LE": 2, "FLOAT_LE": 3, "FLOAT64_LE": 4, "S24_LE": 5}
 KIND = {"coeff": 0, "scale_in": 1, "scale_out": 2, "fscale": 3, "delay": 4}
 
 
-def _write_spec(path, spec, blocks, events):
+def _write_spec(path, spec, blocks, events, f_owner=None):
     rs = spec["rs"]
     dt = np.float32 if rs == 4 else np.float64
     evs = []
@@ -50,16 +51,17 @@ def _write_spec(path, spec, blocks, events):
             else:
                 evs.append((b, 4, ev[1], 0, float(ev[2])))
     with open(path, "wb") as f:
-        f.write(struct.pack("<12i", 0x42465250, spec["L"], spec["N"], rs, spec["n_in"], spec["n_out"],
+        n_procs = 1 + (max(f_owner) if f_owner else 0)
+        f.write(struct.pack("<13i", 0x42465251, spec["L"], spec["N"], rs, spec["n_in"], spec["n_out"],
                             FMT_CODE[spec["infmt"]], FMT_CODE[spec["outfmt"]], len(spec["coeffs"]),
-                            len(spec["filters"]), len(blocks), len(evs)))
+                            len(spec["filters"]), len(blocks), len(evs), n_procs))
         for taps, scale, nb in spec["coeffs"]:
             t = np.ascontiguousarray(taps, dt)
             f.write(struct.pack("<iid", len(t), nb, scale))
             f.write(t.tobytes())
-        for fl in spec["filters"]:
-            f.write(struct.pack("<6i", len(fl["in_ch"]), len(fl["in_f"]), len(fl["out_ch"]), fl["coeff"],
-                                fl["delayblocks"], int(fl["crossfade"])))
+        for fi, fl in enumerate(spec["filters"]):
+            f.write(struct.pack("<7i", f_owner[fi] if f_owner else 0, len(fl["in_ch"]), len(fl["in_f"]), len(fl["out_ch"]),
+                                fl["coeff"], fl["delayblocks"], int(fl["crossfade"])))
             f.write(np.asarray(fl["in_ch"], np.int32).tobytes())
             f.write(np.asarray(fl["in_scale"], np.float64).tobytes())
             f.write(np.asarray(fl["in_f"], np.int32).tobytes())
@@ -177,3 +179,87 @@ def test_reference_filter_process_on_the_reference_s_own_configurations(hip, tmp
             # a sample within one count of the clip level may fall on either side of it
             assert abs(n_over - mine) <= max(2, n_over // 100), (name, ln, mine)
     assert counted > 0 or name != "clip16"
+
+
+def _run_host(exe, tmp_path, tag, spec, blocks, events, f_owner=None, env=None):
+    _write_spec(tmp_path / ("spec_%s.bin" % tag), spec, blocks, events, f_owner)
+    out = tmp_path / ("out_%s.raw" % tag)
+    r = subprocess.run([exe, str(tmp_path / ("spec_%s.bin" % tag)), str(out)], capture_output=True, text=True, timeout=240,
+                       env=dict(os.environ, **(env or {})))
+    assert r.returncode == 0, (tag, r.stdout[-500:], r.stderr[-1500:])
+    return open(out, "rb").read(), [ln for ln in r.stdout.splitlines() if ln.startswith("output ")], r.stderr
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BFHIP_REFLOOP_SEEDS", "24")) // 2))
+def test_the_patched_filter_process_runs_and_its_processes_agree(hip, tmp_path, seed):
+    """patches/bfrun-bfhip.diff applied to the reference's bfrun.c and RUN (oracle/_ref/ref_filter_process_bfhip,
+    -DBF_HAVE_BFHIP): the patched filter_process() takes the fused path -- bfhip_setup() builds the engine
+    from bfconf / icomm / dai_buffer_format in the forked filter process, bfhip_period() forwards the fctrl
+    snapshot and runs the block.  Against the UNPATCHED filter_process() on the same network and control
+    sequence (same tolerance as everywhere), and, with the filters dealt out over two and three filter
+    processes the way bfconf does (connected filters and mixed outputs together, bfconf.c:2893-2931; all
+    processes on the one GPU of the box): **byte-identical** to the patched one-process run -- the host
+    patch's multi-process path, end to end, through the reference's own process code."""
+    from test_gpu_shards import _assign
+    for exe in (EXE, EXE_PATCHED):
+        if not os.path.exists(exe):
+            pytest.fail("%s is missing (built from the reference's bfrun.c in the build container)" % exe)
+    spec, n_blocks, events = fuzz._network(seed + 9000)
+    if seed % 3 == 0:
+        spec["outfmt"] = "S24_4LE"
+    blocks = cases.raw_blocks(seed, n_blocks, spec["L"], spec["n_in"], spec["infmt"], amplitude=0.2)
+    plain, plain_of, _ = _run_host(EXE, tmp_path, "plain", spec, blocks, events)
+    one, one_of, _ = _run_host(EXE_PATCHED, tmp_path, "p1", spec, blocks, events)
+    dis, _, _ = _run_host(EXE_PATCHED, tmp_path, "disabled", spec, blocks, events, env={"BFHIP_DISABLE": "1"})
+    assert dis == plain                          # BFHIP_DISABLE=1: the patched host takes the unfused path, bit for bit
+    rng = np.random.default_rng(seed)
+    for n_proc in (2, 3):
+        f_owner, _ = _assign(spec, n_proc, rng)
+        if len(set(f_owner)) != n_proc:
+            continue                             # a process without filters: bfconf never creates one (bfconf.c:2227-2318)
+        many, many_of, _ = _run_host(EXE_PATCHED, tmp_path, "p%d" % n_proc, spec, blocks, events, f_owner)
+        assert many == one, (seed, n_proc, f_owner)
+        assert many_of == one_of, (seed, n_proc)
+        ref_many, _, _ = _run_host(EXE, tmp_path, "u%d" % n_proc, spec, blocks, events, f_owner)
+        assert ref_many == plain, (seed, n_proc)         # the reference's own multi-process = single-process equality (SURVEY B.5 iii), over the product's ops
+    odt = {"FLOAT_LE": np.float32, "FLOAT64_LE": np.float64, "S24_4LE": np.int32}[spec["outfmt"]]
+    a = np.frombuffer(plain, odt).reshape(n_blocks, spec["L"], spec["n_out"]).astype(np.float64)
+    b = np.frombuffer(one, odt).reshape(n_blocks, spec["L"], spec["n_out"]).astype(np.float64)
+    if spec["outfmt"] == "S24_4LE":
+        assert np.abs(a - b).max() <= 4.0, seed          # (24-bit output of a float32 engine: rounding noise of the round trips)
+    else:
+        tol = 3e-5 if spec["rs"] == 4 else 1e-11
+        scale = float(np.abs(a).max())
+        for blk in range(n_blocks):
+            for ch in range(spec["n_out"]):
+                lvl = max(float(np.sqrt((a[blk][:, ch] ** 2).mean())), 1e-3 * scale, fuzz.FLOOR)
+                assert float(np.sqrt(((a[blk][:, ch] - b[blk][:, ch]) ** 2).mean())) <= tol * lvl, (seed, blk, ch)
+
+
+def test_the_patched_host_prints_its_benchmark_table_with_device_times(hip, tmp_path):
+    """`benchmark: true;` -- the reference prints one row per filter process and ten periods with the
+    time of every stage (bfrun.c:2035-2078).  The patched filter_process() adds the engine's
+    bfhip_engine_stage_times() into t[0..6] before that print: the table the user knows, printed by the
+    reference's own code, with device milliseconds in it (stages fused away read 0)."""
+    if not os.path.exists(EXE_PATCHED):
+        pytest.fail("oracle/_ref/ref_filter_process_bfhip is missing")
+    L, N, I, O = 4096, 4, 3, 4
+    rng = np.random.default_rng(1)
+    spec = dict(L=L, N=N, rs=4, n_in=I, n_out=O, infmt="S24_4LE", outfmt="S24_4LE",
+                coeffs=[(cases.make_ir(rng, L * N, I), 1.0, 0)],
+                filters=[_f(in_ch=[i], out_ch=[o], coeff=0) for o in range(O) for i in range(I)] +
+                        [_f(in_ch=[0, 1], in_scale=[0.5, 0.5], out_ch=[O - 1], coeff=0)])
+    blocks = cases.raw_blocks(2, 31, L, I, "S24_4LE")
+    f_owner = [0 if f["out_ch"][0] < 2 else 1 for f in spec["filters"]]
+    for tag, owner in (("one", None), ("two", f_owner)):
+        _, _, err = _run_host(EXE_PATCHED, tmp_path, "bm_" + tag, spec, blocks, {}, owner, env={"BFREF_BENCHMARK": "1"})
+        rows = [[c.strip() for c in ln.split("|")] for ln in err.splitlines() if ln.count("|") == 10 and "raw2real" not in ln]
+        n_proc = 2 if owner else 1
+        assert len(rows) == n_proc * 3, err[-1500:]                  # 31 periods: three prints per process
+        assert len({row[0] for row in rows}) == n_proc
+        for row in rows:
+            raw2real, time2freq, mix1, conv, mix2, freq2time, real2raw, total = (float(x) for x in row[1:9])
+            assert raw2real == 0 and mix2 == 0 and real2raw == 0, row
+            assert 0 < time2freq < 5 and 0 < conv < 5 and 0 < freq2time < 5 and total > 0, row
+        # the two-input filter's ring fill (mixscale1) runs in the process that owns the last output only
+        assert len({row[0] for row in rows if float(row[3]) > 0}) == 1
