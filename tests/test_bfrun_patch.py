@@ -114,5 +114,14 @@ def test_reference_filter_process_binary_is_built_without_placeholders():
     assert len(ours) >= 15 and all(s.startswith("convolver_") for s in ours), ours     # the convolver.h boundary, nothing else
     dyn = subprocess.run(["nm", "-D", "--defined-only", bf.LIB_PATH], capture_output=True, text=True).stdout.split()
     assert all(s in dyn for s in ours)
+    # the same harness over bfrun.c WITH the host patch applied: the fused entry points come in, the
+    # temporary patched copy is gone after the build
+    exe2 = os.path.join(ROOT, "oracle", "_ref", "ref_filter_process_bfhip")
+    assert os.path.exists(exe2)
+    undef2 = subprocess.run(["nm", "-D", "--undefined-only", exe2], capture_output=True, text=True).stdout.split()
+    fused = sorted(s for s in undef2 if s.startswith("bfhip_"))
+    assert "bfhip_engine_rt_block" in fused and "bfhip_engine_set_filter_active" in fused and "bfhip_engine_stage_times" in fused
+    assert all(s in dyn for s in fused)
+    assert not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "patched"))
     recipe = open(os.path.join(ROOT, "oracle", "Makefile")).read()
     assert "defsym" not in recipe.split("$(FPROC):")[1].split("endif")[0]
