@@ -232,6 +232,15 @@ struct PowerSave {
     int *live;              // [n_in]
 };
 
+// Which channel a transform workgroup takes.  Workgroups b, b + 8, b + 16 ... are dispatched to the same
+// XCD and share its L2; channels that are neighbours in an interleaved frame share cache lines (32
+// four-byte samples per 128 bytes).  Every XCD therefore gets ONE contiguous run of channels: a line
+// of the raw buffer is fetched into one L2 instead of eight, and the 4-byte pieces K3 scatters into a
+// line meet in one L2, which writes whole sectors back instead of eight masked fragments.
+__device__ __forceinline__ int xcd_channel(int b, int n) {
+    return (n & 7) ? b : (b & 7) * (n >> 3) + (b >> 3);
+}
+
 // One workgroup per input channel.  Window = [previous L samples | new L samples]
 // (fftw_convolver.c:181-193); z[n] = x[2n] + i x[2n+1]; complex FFT; untangle; write the
 // packed spectrum into ring slot `slot` of that channel.  All global loads (twiddles,
@@ -365,7 +374,7 @@ fft_in_kernel(const uint8_t *__restrict__ raw, const DevFormat *__restrict__ fmt
               const BlockState *__restrict__ bs, PowerSave ps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (bs) slot = (int)(bs->t % (unsigned int)R);
-    fft_in_body<T, LOG2L, NTP>(blockIdx.x, smem, raw, fmt, prev, ring, tw, R, slot, ps);
+    fft_in_body<T, LOG2L, NTP>(xcd_channel(blockIdx.x, gridDim.x), smem, raw, fmt, prev, ring, tw, R, slot, ps);
 }
 
 // K1 on the wave FFT (fft_wave.h; L = 1024 .. 8192, NT = L/16 threads): same statement as
@@ -495,7 +504,7 @@ fft_in_wave_kernel(const uint8_t *__restrict__ raw, const DevFormat *__restrict_
                    const BlockState *__restrict__ bs, PowerSave ps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (bs) slot = (int)(bs->t % (unsigned int)R);
-    fft_in_wave_body<T, LOG2L>(blockIdx.x, smem, raw, fmt, prev, ring, tw, R, slot, ps);
+    fft_in_wave_body<T, LOG2L>(xcd_channel(blockIdx.x, gridDim.x), smem, raw, fmt, prev, ring, tw, R, slot, ps);
 }
 
 // ------------------------------------------------------------------ K7: taps -> coefficient partition
@@ -1788,7 +1797,7 @@ ifft_out_wave_kernel(const c2<T> *__restrict__ Zp, size_t chunk_stride, int n_ch
                      T *__restrict__ timeout, const c2<T> *__restrict__ tw, double safety_limit,
                      int *__restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    ifft_out_wave_body<T, LOG2L>(blockIdx.x, smem, Zp, chunk_stride, n_chunks, first_channel, fmt, over,
+    ifft_out_wave_body<T, LOG2L>(xcd_channel(blockIdx.x, gridDim.x), smem, Zp, chunk_stride, n_chunks, first_channel, fmt, over,
                                  skip_quant, raw, timeout, tw, safety_limit, status);
 }
 
@@ -1806,10 +1815,10 @@ io_wave_kernel(int n_k3,
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (bs) slot = (int)(bs->t % (unsigned int)R);
     if ((int)blockIdx.x < n_k3)
-        ifft_out_wave_body<T, LOG2L>(blockIdx.x, smem, Zp, chunk_stride, n_chunks, first_channel, fmt_out, over,
+        ifft_out_wave_body<T, LOG2L>(xcd_channel(blockIdx.x, n_k3), smem, Zp, chunk_stride, n_chunks, first_channel, fmt_out, over,
                                      skip_quant, rawout, timeout, tw, safety_limit, status);
     else
-        fft_in_wave_body<T, LOG2L>((int)blockIdx.x - n_k3, smem, rawin, fmt_in, prev, ring, tw, R, slot, ps);
+        fft_in_wave_body<T, LOG2L>(xcd_channel((int)blockIdx.x - n_k3, (int)gridDim.x - n_k3), smem, rawin, fmt_in, prev, ring, tw, R, slot, ps);
 }
 
 template <typename T, int LOG2L, int NTP = fft_threads<T>(LOG2L)>
@@ -1820,7 +1829,7 @@ ifft_out_kernel(const c2<T> *__restrict__ Zp, size_t chunk_stride, int n_chunks,
                 T *__restrict__ timeout, const c2<T> *__restrict__ tw, double safety_limit,
                 int *__restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    ifft_out_body<T, LOG2L, NTP>(blockIdx.x, smem, Zp, chunk_stride, n_chunks, first_channel, fmt, over,
+    ifft_out_body<T, LOG2L, NTP>(xcd_channel(blockIdx.x, gridDim.x), smem, Zp, chunk_stride, n_chunks, first_channel, fmt, over,
                             skip_quant, raw, timeout, tw, safety_limit, status);
 }
 
@@ -1838,10 +1847,10 @@ io_kernel(int n_k3,
           c2<T> *__restrict__ ring, int R, int slot, const c2<T> *__restrict__ tw, PowerSave ps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if ((int)blockIdx.x < n_k3)
-        ifft_out_body<T, LOG2L>(blockIdx.x, smem, Zp, 0, 1, first_channel, fmt_out, over, skip_quant,
+        ifft_out_body<T, LOG2L>(xcd_channel(blockIdx.x, n_k3), smem, Zp, 0, 1, first_channel, fmt_out, over, skip_quant,
                                 rawout, timeout, tw, safety_limit, status);
     else
-        fft_in_body<T, LOG2L>((int)blockIdx.x - n_k3, smem, rawin, fmt_in, prev, ring, tw, R, slot, ps);
+        fft_in_body<T, LOG2L>(xcd_channel((int)blockIdx.x - n_k3, (int)gridDim.x - n_k3), smem, rawin, fmt_in, prev, ring, tw, R, slot, ps);
 }
 
 // ------------------------------------------------------------------ N:1 virtual channels: delay, mute, mix
