@@ -174,6 +174,7 @@ struct DelayLine {
         F = fragment; ss = sample_size;
         int delay = maxd <= 0 ? initdelay : maxd;                      // delay.c:357-360
         if (maxd >= 0 && delay > maxd) delay = initdelay = maxd;
+        if (maxd > 0 && initdelay > maxd) initdelay = maxd;            // (the reference overruns its buffer here)
         curdelay = initdelay; maxdelay = maxd;
         n_full_cap = delay > F ? delay / F + 1 : 0;
         const size_t total = (size_t)(n_full_cap + 4) * frag();
@@ -3022,15 +3023,30 @@ static int finalize_impl(bfhip_engine *e) {
             size_t n_ops_max = 0;
             e->vline[0].assign(e->n_ch[0], DelayLine());
             e->vline[1].assign(e->n_ch[1], DelayLine());
+            // The reference adds the sub-sample filter's integer part to the delay AND to maxdelay
+            // (bfrun.c:1152-1162, 1185-1197) -- also to maxdelay -1 ("cannot be changed"), which turns it
+            // into the limit sdf_length - 1, below the delay it allocates for: delay.c:357-374 then sizes
+            // the buffer for the limit and fills it with the delay (a heap overrun in the reference, found
+            // by tests/test_gpu_refloop.py).  Here a negative maxdelay stays negative (fixed delay), and a
+            // delay above a positive limit starts at the limit -- the clamp delay.c:358-360 means to make.
+            auto limits = [](int delay, int maxd, int extra, int *init_eff, int *max_eff) {
+                *max_eff = maxd < 0 ? maxd : maxd + extra;
+                *init_eff = delay + extra;
+                if (*max_eff > 0 && *init_eff > *max_eff) *init_eff = *max_eff;
+            };
             for (int v : e->vin_list) {
                 const int extra = (side_uses_subdelay(e, 0) && e->sd_slot[0][v] < 0) ? e->sdf_length : 0;    // bfrun.c:1152-1162
-                int rr = e->vline[0][v].init(e->L, e->vdelay[0][v] + extra, e->vmaxdelay[0][v] + extra, e->fmt[0][e->v2p[0][v]].bytes);
+                int d0, m0;
+                limits(e->vdelay[0][v], e->vmaxdelay[0][v], extra, &d0, &m0);
+                int rr = e->vline[0][v].init(e->L, d0, m0, e->fmt[0][e->v2p[0][v]].bytes);
                 if (rr != BFHIP_OK) return fail(rr, "delay buffer allocation failed");
                 n_ops_max += e->vline[0][v].n_full_cap + 10;
             }
             for (auto &g : e->vout_groups) for (int v : g) {
                 const int extra = (side_uses_subdelay(e, 1) && e->sd_slot[1][v] < 0 && g.size() > 1) ? e->sdf_length : 0;
-                int rr = g.size() > 1 ? e->vline[1][v].init(e->L, e->vdelay[1][v] + extra, e->vmaxdelay[1][v] + extra, e->rs)
+                int d1, m1;
+                limits(e->vdelay[1][v], e->vmaxdelay[1][v], extra, &d1, &m1);
+                int rr = g.size() > 1 ? e->vline[1][v].init(e->L, d1, m1, e->rs)
                                       : e->vline[1][v].init(e->L, 0, 0, e->rs);     // 1:1: dai.c delays it
                 if (rr != BFHIP_OK) return fail(rr, "delay buffer allocation failed");
                 n_ops_max += e->vline[1][v].n_full_cap + 10;

@@ -883,6 +883,21 @@ bfo_engine_enable_subdelay(bfo_engine *e, int sdf_length, double beta)
 
 void bfo_engine_set_subdelay(bfo_engine *e, int io, int ch, int subdelay) { e->subdelay[io][ch] = subdelay; }
 
+/* What filter_process() hands delay_allocate_buffer() for a channel that shares a physical one
+   (bfrun.c:1152-1162, 1185-1197): delay + extra and maxdelay + extra, extra = the sub-sample filter's
+   integer part on channels without a filter of their own.  Where that leaves the reference's own
+   buffer too small -- maxdelay -1 becomes the limit extra - 1, below the delay; delay.c:357-374 then
+   allocates for the limit and fills for the delay: a heap overrun in the reference -- the engines
+   agree on: a negative maxdelay stays negative (fixed delay), a delay above a positive limit starts
+   at the limit. */
+static void
+vdelay_limits(int delay, int maxdelay, int extra, int *init_eff, int *max_eff)
+{
+    *max_eff = maxdelay < 0 ? maxdelay : maxdelay + extra;
+    *init_eff = delay + extra;
+    if (*max_eff > 0 && *init_eff > *max_eff) *init_eff = *max_eff;
+}
+
 static int
 side_uses_subdelay(const bfo_engine *e, int io)
 {
@@ -1035,9 +1050,11 @@ bfo_engine_block(bfo_engine *e, const void *rawin, void *rawout)
                 /* channels without a sub-sample filter are delayed by its integer part
                    (bfrun.c:1152-1162, 1512-1516) */
                 const int extra = (side_uses_subdelay(e, 0) && e->subdelay[0][n] == -100) ? e->sdf_length : 0;
-                if (e->db[0][n] == NULL)
-                    e->db[0][n] = bfo_delay_new(e->L, e->delay[0][n] + extra,
-                                                e->maxdelay[0][n] + extra, bf->bytes);
+                if (e->db[0][n] == NULL) {
+                    int d0, m0;
+                    vdelay_limits(e->delay[0][n], e->maxdelay[0][n], extra, &d0, &m0);
+                    e->db[0][n] = bfo_delay_new(e->L, d0, m0, bf->bytes);
+                }
                 bfo_delay_update(e->db[0][n], e->incopy, e->delay[0][n] + extra);
             } else {
                 memset(e->incopy, 0, (size_t)e->L * bf->bytes);
@@ -1168,8 +1185,11 @@ bfo_engine_block(bfo_engine *e, const void *rawin, void *rawout)
             } else {
                 /* :1938-2003 */
                 const int extra = (side_uses_subdelay(e, 1) && e->subdelay[1][n] == -100) ? e->sdf_length : 0;
-                if (e->db[1][n] == NULL)
-                    e->db[1][n] = bfo_delay_new(e->L, e->delay[1][n] + extra, e->maxdelay[1][n] + extra, e->rs);
+                if (e->db[1][n] == NULL) {
+                    int d1, m1;
+                    vdelay_limits(e->delay[1][n], e->maxdelay[1][n], extra, &d1, &m1);
+                    e->db[1][n] = bfo_delay_new(e->L, d1, m1, e->rs);
+                }
                 bfo_delay_update(e->db[1][n], e->tmp_out, e->delay[1][n] + extra);
                 if (!e->muted[1][n]) {
                     if (!filled) {

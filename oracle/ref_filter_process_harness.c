@@ -24,6 +24,10 @@
  * structure bfconf.c would fill from a configuration file (its lexer needs flex, absent here), the
  * dai_buffer_format tables dai_init() would fill from opened devices, and the input / output
  * process on the other end of the pipes.  Spec file format: tests/test_gpu_refloop.py writes it.
+ * A spec may carry a channel section (magic ...53): N:1 virtual -> physical maps, integer delays with
+ * their maxima, mutes, sub-sample delays, dither flags -- then bfrun.c:1128-1198, 1505-1531 and
+ * 1938-2003 (delay, mute and mix of channels that share a physical one) run too, with the reference's
+ * own delay.c and dither.c underneath.
  *
  *   ref_filter_process <spec file> <raw output file>
  */
@@ -31,6 +35,7 @@
 #include <sys/wait.h>
 
 #include "bfrun.c"
+#include "dither.h"
 
 struct bfconf *bfconf = NULL;
 
@@ -95,15 +100,20 @@ main(int argc, char *argv[])
     uint8_t *rawin;
     size_t in_bytes, out_bytes;
     char tok = 0;
+    int ext, n_phys[2], sdf_length = -1;
+    int32_t *x_v2p[2] = { NULL, NULL }, *x_delay[2], *x_maxdelay[2], *x_mute[2], *x_subdelay[2], *x_dither = NULL;
+    double sdf_beta = 9.0;
 
     if (argc != 3 || (f = fopen(argv[1], "rb")) == NULL) {
         fprintf(stderr, "usage: ref_filter_process spec out.raw\n");
         return 2;
     }
-    if (rd32(f) != 0x42465251) {
+    ext = rd32(f);
+    if (ext != 0x42465251 && ext != 0x42465253) {
         fprintf(stderr, "ref_filter_process: bad magic\n");
         return 2;
     }
+    ext = ext == 0x42465253;
     L = rd32(f); N = rd32(f); rs = rd32(f);
     n_ch[IN] = rd32(f); n_ch[OUT] = rd32(f);
     fmt[IN] = rd32(f); fmt[OUT] = rd32(f);
@@ -114,8 +124,30 @@ main(int argc, char *argv[])
         return 2;
     }
 
-    /* ---- what bfconf_init() leaves behind (bfconf.c:2786 ff.), for a configuration without N:1
-       channels, delays, dither or modules */
+    n_phys[IN] = n_ch[IN];
+    n_phys[OUT] = n_ch[OUT];
+    if (ext) {
+        /* the channel section: per side the physical channel count and, per virtual channel, its
+           physical channel, delay, maxdelay, mute, subdelay; then the dither flag of every physical
+           output, sdf_length and sdf_beta */
+        FOR_IN_AND_OUT {
+            n_phys[IO] = rd32(f);
+            x_v2p[IO] = emalloc((n_ch[IO] + 1) * 4); rd(f, x_v2p[IO], n_ch[IO] * 4);
+            x_delay[IO] = emalloc((n_ch[IO] + 1) * 4); rd(f, x_delay[IO], n_ch[IO] * 4);
+            x_maxdelay[IO] = emalloc((n_ch[IO] + 1) * 4); rd(f, x_maxdelay[IO], n_ch[IO] * 4);
+            x_mute[IO] = emalloc((n_ch[IO] + 1) * 4); rd(f, x_mute[IO], n_ch[IO] * 4);
+            x_subdelay[IO] = emalloc((n_ch[IO] + 1) * 4); rd(f, x_subdelay[IO], n_ch[IO] * 4);
+            if (n_phys[IO] < 1 || n_phys[IO] > n_ch[IO]) {
+                fprintf(stderr, "ref_filter_process: bad channel section\n");
+                return 2;
+            }
+        }
+        x_dither = emalloc((n_phys[OUT] + 1) * 4); rd(f, x_dither, n_phys[OUT] * 4);
+        sdf_length = rd32(f);
+        rd(f, &sdf_beta, 8);
+    }
+
+    /* ---- what bfconf_init() leaves behind (bfconf.c:2786 ff.), for a configuration without modules */
     bfconf = &conf;
     memset(&conf, 0, sizeof(conf));
     conf.cpu_mhz = 1000.0;
@@ -131,38 +163,91 @@ main(int argc, char *argv[])
     if (!convolver_init(NULL, L, rs)) {
         return 2;
     }
+    conf.sdf_length = sdf_length;
+    conf.sdf_beta = sdf_beta;
     FOR_IN_AND_OUT {
-        conf.n_channels[IO] = conf.n_physical_channels[IO] = n_ch[IO];
-        conf.n_virtperphys[IO] = emalloc(n_ch[IO] * sizeof(int));
-        conf.phys2virt[IO] = emalloc(n_ch[IO] * sizeof(int *));
+        conf.n_channels[IO] = n_ch[IO];
+        conf.n_physical_channels[IO] = n_phys[IO];
+        conf.n_virtperphys[IO] = emalloc(n_phys[IO] * sizeof(int));
+        conf.phys2virt[IO] = emalloc(n_phys[IO] * sizeof(int *));
         conf.virt2phys[IO] = emalloc(n_ch[IO] * sizeof(int));
         conf.delay[IO] = emalloc(n_ch[IO] * sizeof(int));
         conf.maxdelay[IO] = emalloc(n_ch[IO] * sizeof(int));
         conf.mute[IO] = emalloc(n_ch[IO] * sizeof(bool_t));
         conf.subdelay[IO] = emalloc(n_ch[IO] * sizeof(int));
+        for (n = 0; n < n_phys[IO]; n++) {
+            conf.n_virtperphys[IO][n] = 0;
+            conf.phys2virt[IO][n] = emalloc((n_ch[IO] + 1) * sizeof(int));
+        }
         for (n = 0; n < n_ch[IO]; n++) {
-            conf.n_virtperphys[IO][n] = 1;
-            conf.phys2virt[IO][n] = emalloc(sizeof(int));
-            conf.phys2virt[IO][n][0] = n;
-            conf.virt2phys[IO][n] = n;
-            conf.delay[IO][n] = conf.maxdelay[IO][n] = 0;
-            conf.mute[IO][n] = false;
-            conf.subdelay[IO][n] = BF_UNDEFINED_SUBDELAY;
+            /* a physical channel's virtual ones in ascending order (bfconf.c:1355-1379) */
+            const int p = ext ? x_v2p[IO][n] : n;
+            if (p < 0 || p >= n_phys[IO]) {
+                fprintf(stderr, "ref_filter_process: bad channel map\n");
+                return 2;
+            }
+            conf.virt2phys[IO][n] = p;
+            conf.phys2virt[IO][p][conf.n_virtperphys[IO][p]++] = n;
+            conf.delay[IO][n] = ext ? x_delay[IO][n] : 0;
+            conf.maxdelay[IO][n] = ext ? x_maxdelay[IO][n] : 0;
+            conf.mute[IO][n] = ext ? !!x_mute[IO][n] : false;
+            conf.subdelay[IO][n] = ext ? x_subdelay[IO][n] : BF_UNDEFINED_SUBDELAY;
+            if (conf.subdelay[IO][n] != BF_UNDEFINED_SUBDELAY) {
+                conf.use_subdelay[IO] = true;           /* bfconf.c:1343-1351 */
+            }
         }
         dai_buffer_format[IO] = emalloc(sizeof(struct dai_buffer_format));
         memset(dai_buffer_format[IO], 0, sizeof(struct dai_buffer_format));
         dai_buffer_format[IO]->n_samples = L;
-        dai_buffer_format[IO]->n_channels = n_ch[IO];
-        for (n = 0; n < n_ch[IO]; n++) {
+        dai_buffer_format[IO]->n_channels = n_phys[IO];
+        for (n = 0; n < n_phys[IO]; n++) {
             /* one interleaved device with all channels open (dai.c:537-576) */
             set_format(&dai_buffer_format[IO]->bf[n].sf, fmt[IO]);
-            dai_buffer_format[IO]->bf[n].sample_spacing = n_ch[IO];
+            dai_buffer_format[IO]->bf[n].sample_spacing = n_phys[IO];
             dai_buffer_format[IO]->bf[n].byte_offset = n * dai_buffer_format[IO]->bf[n].sf.bytes;
         }
-        dai_buffer_format[IO]->n_bytes = L * n_ch[IO] * dai_buffer_format[IO]->bf[0].sf.bytes;
+        dai_buffer_format[IO]->n_bytes = L * n_phys[IO] * dai_buffer_format[IO]->bf[0].sf.bytes;
+        /* that device as bfconf describes it (bfrun.c:1144-1164 looks a channel's sample size up here) */
+        conf.n_subdevs[IO] = 1;
+        conf.subdevs[IO] = emalloc(sizeof(struct dai_subdevice));
+        memset(conf.subdevs[IO], 0, sizeof(struct dai_subdevice));
+        conf.subdevs[IO][0].channels.sf = dai_buffer_format[IO]->bf[0].sf;
+        conf.subdevs[IO][0].channels.open_channels = conf.subdevs[IO][0].channels.used_channels = n_phys[IO];
+        conf.subdevs[IO][0].channels.channel_selection = emalloc(n_phys[IO] * sizeof(int));
+        conf.subdevs[IO][0].channels.channel_name = emalloc(n_phys[IO] * sizeof(int));
+        for (n = 0; n < n_phys[IO]; n++) {
+            conf.subdevs[IO][0].channels.channel_selection[n] = conf.subdevs[IO][0].channels.channel_name[n] = n;
+        }
     }
-    conf.dither_state = emalloc(n_ch[OUT] * sizeof(struct dither_state *));
-    memset(conf.dither_state, 0, n_ch[OUT] * sizeof(struct dither_state *));
+    if (sdf_length < 0) {
+        conf.use_subdelay[IN] = conf.use_subdelay[OUT] = false;         /* bfconf.c:2796-2798 */
+    }
+    if ((conf.use_subdelay[IN] || conf.use_subdelay[OUT]) &&
+        !delay_subsample_init(BF_SAMPLE_SLOTS, conf.sdf_length, conf.sdf_beta, L, rs))      /* bfconf.c:2806-2816 */
+    {
+        fprintf(stderr, "ref_filter_process: delay_subsample_init failed\n");
+        return 2;
+    }
+    /* dither (bfconf.c:3176-3240): one state per flagged physical output, in channel order */
+    conf.dither_state = emalloc(n_phys[OUT] * sizeof(struct dither_state *));
+    memset(conf.dither_state, 0, n_phys[OUT] * sizeof(struct dither_state *));
+    if (ext) {
+        struct dither_state *states[BF_MAXCHANNELS];
+        for (n = j = 0; n < n_phys[OUT]; n++) {
+            j += !!x_dither[n];
+        }
+        if (j > 0) {
+            if (!dither_init(j, conf.sampling_rate, rs, conf.max_dither_table_size, L, states)) {
+                fprintf(stderr, "ref_filter_process: dither_init failed\n");
+                return 2;
+            }
+            for (n = j = 0; n < n_phys[OUT]; n++) {
+                if (x_dither[n]) {
+                    conf.dither_state[n] = states[j++];
+                }
+            }
+        }
+    }
 
     /* coefficient sets the way load_coeff() prepares them (bfconf.c:1979-2019): one
        convolver_coeffs2cbuf() per block of L taps */
@@ -288,8 +373,17 @@ main(int argc, char *argv[])
     }
     icomm->n_pids = 0;
     icomm->exit_status = BF_EXIT_OK;
+    FOR_IN_AND_OUT {                    /* bfrun.c:2200-2211 */
+        for (n = 0; n < n_ch[IO]; n++) {
+            icomm->delay[IO][n] = conf.delay[IO][n];
+            icomm->subdelay[IO][n] = conf.subdelay[IO][n];
+            if (conf.mute[IO][n]) {
+                bit_set_volatile(icomm->ismuted[IO], n);
+            }
+        }
+    }
     for (n = 0; n < n_ch[OUT]; n++) {
-        struct sample_format *sf = &dai_buffer_format[OUT]->bf[n].sf;
+        struct sample_format *sf = &dai_buffer_format[OUT]->bf[conf.virt2phys[OUT][n]].sf;
         icomm->overflow[n].max = sf->isfloat ? 1.0 : (double)((uint64_t)1 << ((sf->sbytes << 3) - 1)) - 1;
     }
     if (pipe(mutex_pipe) == -1 || pipe(in_pipe) == -1 || pipe(out_pipe) == -1 || !writefd(mutex_pipe[1], &tok, 1)) {
@@ -376,7 +470,23 @@ main(int argc, char *argv[])
             case 1: icomm->fctrl[ev[i].filter].scale[IN][ev[i].index] = ev[i].value; break;
             case 2: icomm->fctrl[ev[i].filter].scale[OUT][ev[i].index] = ev[i].value; break;
             case 3: icomm->fctrl[ev[i].filter].fscale[ev[i].index] = ev[i].value; break;
-            default: icomm->fctrl[ev[i].filter].delayblocks = (int)ev[i].value; break;
+            case 4: icomm->fctrl[ev[i].filter].delayblocks = (int)ev[i].value; break;
+            /* what bfaccess->toggle_mute / set_delay / set_subdelay leave in icomm for channels that
+               share a physical one (bfrun.c:458-541; for 1:1 channels they go on to dai.c, which the
+               filter process never sees): filter = side, index = virtual channel */
+            case 5:
+                if (ev[i].value != 0) {
+                    bit_set_volatile(icomm->ismuted[ev[i].filter], ev[i].index);
+                } else {
+                    bit_clr_volatile(icomm->ismuted[ev[i].filter], ev[i].index);
+                }
+                break;
+            case 6:
+                if ((int)ev[i].value >= 0 && (int)ev[i].value <= conf.maxdelay[ev[i].filter][ev[i].index]) {      /* set_delay's check, bfrun.c:495 */
+                    icomm->delay[ev[i].filter][ev[i].index] = (int)ev[i].value;
+                }
+                break;
+            default: icomm->subdelay[ev[i].filter][ev[i].index] = (int)ev[i].value; break;
             }
             icomm_mutex(0);
         }

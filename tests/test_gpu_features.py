@@ -471,6 +471,52 @@ def test_subsample_delay_inputs_and_outputs(hip, rs):
         assert cases.rel_rms(gsamp, osamp) <= tol, (b, cases.rel_rms(gsamp, osamp))
 
 
+def test_fixed_delays_beside_a_subsample_filter_stay_inside_their_buffers(hip):
+    """maxdelay -1 (the reference's default: "cannot be changed") on a channel that shares a physical
+    one, beside a sub-sample filter on the same side.  The reference adds sdf_length to delay AND
+    maxdelay (bfrun.c:1152-1162, 1185-1197): the limit becomes sdf_length - 1, below the delay, and
+    delay.c:357-374 allocates for the limit and fills for the delay -- a heap overrun in the reference
+    (tests/test_gpu_refloop.py met it as "corrupted double-linked list"; the engine's mirror of that
+    arithmetic was a memory fault on the GPU).  Defined here: the delay is what was asked
+    for plus sdf_length and cannot be changed; a delay above a positive limit starts at the limit."""
+    L, N, half = 64, 2, 15
+    ofmt = "FLOAT_LE"
+
+    def mk(cls):
+        e = cls(L, N, 4, 3, 3)
+        e.map_channels(0, [0, 0, 1])
+        e.map_channels(1, [0, 0, 1])
+        e.set_interleaved_phys(0, "FLOAT_LE", 2)
+        e.set_interleaved_phys(1, ofmt, 2)
+        e.enable_subdelay(half)
+        e.set_subdelay(0, 0, 0)                  # virtual input 0 filtered: input 1 gets sdf_length more
+        e.set_subdelay(1, 0, 0)                  # the same on the output side
+        for io in range(2):
+            e.set_maxdelay(io, 1, -1); e.set_delay(io, 1, 700 if io == 0 else 20)
+            e.set_maxdelay(io, 0, 40); e.set_delay(io, 0, 90)          # above its limit: starts at 40
+        e.add_filter(in_ch=[1], out_ch=[1], coeff=-1)
+        e.add_filter(in_ch=[0], out_ch=[0], coeff=-1, in_scale=[0.0])
+        e.add_filter(in_ch=[2], out_ch=[2], coeff=-1)
+        if hasattr(e, "finalize"):
+            e.finalize()
+        return e
+    ge, oe = mk(hip.Engine), mk(bo.Engine)
+    x = np.zeros((16 * L, 2), np.float32)
+    x[5, 0] = 1.0
+    got = []
+    for b in range(16):
+        if b == 3:
+            for eng in (ge, oe):
+                eng.set_delay(0, 1, 10)          # refused: the delay is fixed
+        gs, g = ge.block(x[b * L:(b + 1) * L])
+        os_, o = oe.block(x[b * L:(b + 1) * L])
+        assert gs == os_ == 0
+        assert np.abs(cases.samples(g, ofmt) - cases.samples(o, ofmt)).max() <= 2e-5, b        # (an impulse of 1.0)
+        got.append(cases.samples(g, ofmt).reshape(L, 2)[:, 0])
+    y = np.concatenate(got)
+    assert int(np.argmax(np.abs(y))) == 5 + (700 + half) + (20 + half) and abs(y.max() - 1.0) < 1e-5
+
+
 def test_prewarm_changes_cost_not_results(hip):
     """bfhip_engine_prewarm: rings declared full of silence; outputs identical to a cold start,
     including for a ring depth that is not a power of two (unsigned wrap of blockcounter - p)"""

@@ -36,7 +36,12 @@ FMT_CODE = {"S16_LE": 0, "S24_4LE": 1, "S32_LE": 2, "FLOAT_LE": 3, "FLOAT64_LE":
 KIND = {"coeff": 0, "scale_in": 1, "scale_out": 2, "fscale": 3, "delay": 4}
 
 
+UNDEF_SUBDELAY = -100          # BF_UNDEFINED_SUBDELAY (bfmod.h:89-90)
+
+
 def _write_spec(path, spec, blocks, events, f_owner=None):
+    """spec["channels"] (optional): dict(maps=[v2p_in, v2p_out], delay, maxdelay, mute, subdelay (each
+    [per virtual input, per virtual output]), dither=[flag per physical output], sdf_length, sdf_beta)"""
     rs = spec["rs"]
     dt = np.float32 if rs == 4 else np.float64
     evs = []
@@ -48,13 +53,27 @@ def _write_spec(path, spec, blocks, events, f_owner=None):
                 evs.append((b, 1 if ev[2] == 0 else 2, ev[1], ev[3], float(ev[4])))
             elif ev[0] == "fscale":
                 evs.append((b, 3, ev[1], ev[2], float(ev[3])))
-            else:
+            elif ev[0] == "delayblocks" or (ev[0] == "delay" and len(ev) == 3):
                 evs.append((b, 4, ev[1], 0, float(ev[2])))
+            elif ev[0] == "mute":                       # ("mute", io, virtual channel, on)
+                evs.append((b, 5, ev[1], ev[2], float(ev[3])))
+            elif ev[0] == "delay":                      # ("delay", io, virtual channel, samples)
+                evs.append((b, 6, ev[1], ev[2], float(ev[3])))
+            else:                                       # ("subdelay", io, virtual channel, slots)
+                evs.append((b, 7, ev[1], ev[2], float(ev[3])))
     with open(path, "wb") as f:
         n_procs = 1 + (max(f_owner) if f_owner else 0)
-        f.write(struct.pack("<13i", 0x42465251, spec["L"], spec["N"], rs, spec["n_in"], spec["n_out"],
+        ch = spec.get("channels")
+        f.write(struct.pack("<13i", 0x42465253 if ch else 0x42465251, spec["L"], spec["N"], rs, spec["n_in"], spec["n_out"],
                             FMT_CODE[spec["infmt"]], FMT_CODE[spec["outfmt"]], len(spec["coeffs"]),
                             len(spec["filters"]), len(blocks), len(evs), n_procs))
+        if ch:
+            for io in range(2):
+                f.write(struct.pack("<i", max(ch["maps"][io]) + 1))
+                for key in ("maps", "delay", "maxdelay", "mute", "subdelay"):
+                    f.write(np.asarray(ch[key][io], np.int32).tobytes())
+            f.write(np.asarray(ch["dither"], np.int32).tobytes())
+            f.write(struct.pack("<id", ch.get("sdf_length", -1), ch.get("sdf_beta", 9.0)))
         for taps, scale, nb in spec["coeffs"]:
             t = np.ascontiguousarray(taps, dt)
             f.write(struct.pack("<iid", len(t), nb, scale))
@@ -263,3 +282,121 @@ def test_the_patched_host_prints_its_benchmark_table_with_device_times(hip, tmp_
             assert 0 < time2freq < 5 and 0 < conv < 5 and 0 < freq2time < 5 and total > 0, row
         # the two-input filter's ring fill (mixscale1) runs in the process that owns the last output only
         assert len({row[0] for row in rows if float(row[3]) > 0}) == 1
+
+
+def _channel_case(seed):
+    """test_gpu_fuzz's random N:1 cases (maps, integer delays in every regime of delay.c, run-time delay
+    changes and mutes), on integer outputs with dither on some physical outputs for every third seed and
+    sub-sample delays on some channels for every fourth"""
+    c = fuzz._vchan_case(seed)
+    rng = np.random.default_rng(seed + 77)
+    n_phys_out = max(c["maps"][1]) + 1
+    c["outfmt"] = ["S16_LE", "S24_4LE", cases_float(c["rs"])][seed % 3]
+    c["dither"] = [int(rng.random() < 0.6) if c["outfmt"] == "S16_LE" else 0 for _ in range(n_phys_out)]
+    c["sdf_length"], c["subdelay"] = -1, [[UNDEF_SUBDELAY] * c["nv"][io] for io in range(2)]
+    if seed % 4 == 3:
+        c["sdf_length"] = int(rng.choice([3, 7, 15]))
+        if 2 * c["sdf_length"] + 1 > c["L"]:
+            c["sdf_length"] = 3
+        for io in range(2):
+            for v in range(c["nv"][io]):
+                if rng.random() < 0.5:
+                    c["subdelay"][io][v] = int(rng.integers(-99, 100))
+        # A channel that shares a physical one and has no filter of its own is delayed by sdf_length more,
+        # and the reference adds sdf_length to its maxdelay too (bfrun.c:1152-1162, 1185-1197) -- also to
+        # the default -1, which makes it a limit BELOW the delay; delay.c:357-374 then allocates for the
+        # limit and fills for the delay.  The reference overruns its heap there (this test found it:
+        # "corrupted double-linked list" in the unpatched host); such channels get a real maxdelay here,
+        # and test_gpu_features holds the engine to its own defined answer for them.
+        for io in range(2):
+            if not any(sd != UNDEF_SUBDELAY for sd in c["subdelay"][io]):
+                continue
+            for v in range(c["nv"][io]):
+                shared = c["maps"][io].count(c["maps"][io][v]) > 1
+                if shared and c["subdelay"][io][v] == UNDEF_SUBDELAY and c["maxd"][io][v] < 0:
+                    c["maxd"][io][v] = 1200
+    return c
+
+
+def cases_float(rs):
+    return "FLOAT_LE" if rs == 4 else "FLOAT64_LE"
+
+
+def _channel_engine(cls, c):
+    e = cls(c["L"], c["N"], c["rs"], c["nv"][0], c["nv"][1])
+    e.map_channels(0, c["maps"][0])
+    e.map_channels(1, c["maps"][1])
+    e.set_interleaved_phys(0, c["infmt"], max(c["maps"][0]) + 1)
+    e.set_interleaved_phys(1, c["outfmt"], max(c["maps"][1]) + 1)
+    if c["sdf_length"] > 0:
+        e.enable_subdelay(c["sdf_length"], 9.0)
+    if any(c["dither"]):
+        e.enable_dither([p for p, d in enumerate(c["dither"]) if d], 44100)
+    for h in c["coeffs"]:
+        e.add_coeff(h)
+    for io in range(2):
+        for v in range(c["nv"][io]):
+            e.set_delay(io, v, c["delay"][io][v])
+            e.set_maxdelay(io, v, c["maxd"][io][v])
+            if c["sdf_length"] > 0 and c["subdelay"][io][v] != UNDEF_SUBDELAY:
+                e.set_subdelay(io, v, c["subdelay"][io][v])
+    for f in c["filters"]:
+        e.add_filter(**f)
+    if hasattr(e, "finalize"):
+        e.finalize()
+    return e
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BFHIP_REFLOOP_SEEDS", "24"))))
+def test_reference_filter_process_with_shared_channels_delays_mutes_dither_subdelay(hip, tmp_path, seed):
+    """bfrun.c:1128-1198, 1505-1531, 1938-2003 -- virtual channels that share a physical one are delayed
+    (the reference's delay.c), muted and mixed inside filter_process(); the HP-TPDF dither of the
+    reference's dither.c and its sub-sample delay filters (delay.c:416-505, over the product's
+    convolver_td_* ops) ride along.  The reference's loop over the product's per-block ops, the PATCHED
+    loop (fused engine built by bfhip_setup() from the same bfconf), the engine driven directly and the
+    oracle, on the same random cases as test_gpu_fuzz's channel test."""
+    for exe in (EXE, EXE_PATCHED):
+        if not os.path.exists(exe):
+            pytest.fail("%s is missing (built from the reference's bfrun.c in the build container)" % exe)
+    c = _channel_case(seed)
+    n_phys_in, n_phys_out = max(c["maps"][0]) + 1, max(c["maps"][1]) + 1
+    spec = dict(L=c["L"], N=c["N"], rs=c["rs"], n_in=c["nv"][0], n_out=c["nv"][1], infmt=c["infmt"], outfmt=c["outfmt"],
+                coeffs=[(h, 1.0, 0) for h in c["coeffs"]], filters=[_f(**f) for f in c["filters"]],
+                channels=dict(maps=c["maps"], delay=c["delay"], maxdelay=c["maxd"], mute=[[0] * c["nv"][0], [0] * c["nv"][1]],
+                              subdelay=c["subdelay"], dither=c["dither"], sdf_length=c["sdf_length"]))
+    blocks = cases.raw_blocks(seed, c["n_blocks"], c["L"], n_phys_in, c["infmt"], amplitude=0.2)
+    plain, plain_of, _ = _run_host(EXE, tmp_path, "plain", spec, blocks, c["events"])
+    fused, fused_of, _ = _run_host(EXE_PATCHED, tmp_path, "fused", spec, blocks, c["events"])
+    odt = {"FLOAT_LE": np.float32, "FLOAT64_LE": np.float64, "S24_4LE": np.int32, "S16_LE": np.int16}[c["outfmt"]]
+    ref = np.frombuffer(plain, odt).reshape(c["n_blocks"], c["L"], n_phys_out).astype(np.float64)
+    pat = np.frombuffer(fused, odt).reshape(c["n_blocks"], c["L"], n_phys_out).astype(np.float64)
+    ge, oe = _channel_engine(hip.Engine, c), _channel_engine(bo.Engine, c)
+    tol = 3e-5 if c["rs"] == 4 else 1e-11
+    scale = float(np.abs(ref).max())
+    for b, blk in enumerate(blocks):
+        for eng in (ge, oe):
+            for kind, io, v, val in c["events"].get(b, []):
+                (eng.set_delay if kind == "delay" else eng.set_mute)(io, v, val)
+        gs, g = ge.block(blk)
+        os_, o = oe.block(blk)
+        assert gs == os_ == 0, (seed, b)
+        got = {"patched host": pat[b],
+               "fused engine": np.frombuffer(g.tobytes(), odt).reshape(c["L"], n_phys_out).astype(np.float64),
+               "oracle": np.frombuffer(o.tobytes(), odt).reshape(c["L"], n_phys_out).astype(np.float64)}
+        for who, arr in got.items():
+            if c["outfmt"] in ("S16_LE", "S24_4LE"):
+                # one count: a sample on a rounding boundary.  A dithered channel may differ by two: the
+                # HP-TPDF quantiser feeds its error back with coefficients {1, -1} (dither_funs.h:20-27), so
+                # one rounding decision that falls the other way moves the next two samples by a count
+                # each way on top of their own rounding
+                lim = 4.0 if c["outfmt"] == "S24_4LE" else 1.0
+                dith = np.asarray(c["dither"], bool)
+                d = np.abs(arr - ref[b]).max(axis=0)
+                assert (d[~dith] <= lim).all() and (d[dith] <= 2.0).all(), (who, seed, b, d)
+                continue
+            else:
+                for ch in range(n_phys_out):
+                    lvl = max(float(np.sqrt((ref[b][:, ch] ** 2).mean())), 1e-3 * scale, fuzz.FLOOR)
+                    err = float(np.sqrt(((arr[:, ch] - ref[b][:, ch]) ** 2).mean()))
+                    assert err <= tol * lvl, (who, seed, b, ch, err, lvl)
+    assert len(plain_of) == len(fused_of) == c["nv"][1]
