@@ -400,3 +400,16 @@ def test_reference_filter_process_with_shared_channels_delays_mutes_dither_subde
                     err = float(np.sqrt(((arr[:, ch] - ref[b][:, ch]) ** 2).mean()))
                     assert err <= tol * lvl, (who, seed, b, ch, err, lvl)
     assert len(plain_of) == len(fused_of) == c["nv"][1]
+    # ... and dealt out over two and three filter processes (the members of a shared physical output in
+    # one process, bfconf.c:2893-2931): the same bytes as one process, patched and unpatched
+    from test_gpu_shards import _assign
+    by_phys = dict(spec, filters=[dict(f, out_ch=[c["maps"][1][o] for o in f["out_ch"]]) for f in spec["filters"]])
+    rng = np.random.default_rng(seed)
+    for n_proc in (2, 3):
+        f_owner, _ = _assign(by_phys, n_proc, rng)
+        if len(set(f_owner)) != n_proc:
+            continue
+        many, many_of, _ = _run_host(EXE_PATCHED, tmp_path, "p%d" % n_proc, spec, blocks, c["events"], f_owner)
+        assert many == fused and many_of == fused_of, (seed, n_proc, f_owner)
+        ref_many, ref_many_of, _ = _run_host(EXE, tmp_path, "u%d" % n_proc, spec, blocks, c["events"], f_owner)
+        assert ref_many == plain and ref_many_of == plain_of, (seed, n_proc, f_owner)

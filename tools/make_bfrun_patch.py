@@ -55,10 +55,10 @@ bfhip_die(const char what[])
     bf_exit(BF_EXIT_OTHER);
 }
 
-/* which process mixes (and therefore, on the GPU, converts) a virtual output; outputs no
-   filter feeds belong to process 0 */
+/* the process whose filters feed a virtual output (bfconf puts all filters of one output, and of
+   the members of one physical output, into one process, bfconf.c:2893-2931), or -1 */
 static int
-bfhip_output_owner(int virtch)
+bfhip_output_feeder(int virtch)
 {
     int k, i;
 
@@ -67,6 +67,27 @@ bfhip_output_owner(int virtch)
             if (bfconf->fproc[k].unique_channels[OUT][i] == virtch) {
                 return k;
             }
+        }
+    }
+    return -1;
+}
+
+/* which process mixes (and therefore, on the GPU, converts) a virtual output.  An output no
+   filter feeds (bfconf only warns, bfconf.c:2708) goes with the fed members of its physical
+   channel, so that one engine mixes the whole group; a physical channel nobody feeds at all
+   belongs to process 0 */
+static int
+bfhip_output_owner(int virtch)
+{
+    int k, i, physch;
+
+    if ((k = bfhip_output_feeder(virtch)) >= 0) {
+        return k;
+    }
+    physch = bfconf->virt2phys[OUT][virtch];
+    for (i = 0; i < bfconf->n_virtperphys[OUT][physch]; i++) {
+        if ((k = bfhip_output_feeder(bfconf->phys2virt[OUT][physch][i])) >= 0) {
+            return k;
         }
     }
     return 0;
