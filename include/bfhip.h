@@ -221,7 +221,8 @@ int bfhip_engine_add_filter(bfhip_engine *e,
    pass skips foreign channels) and by the host ones (bfhip_engine_block, bfhip_engine_rt_wait copy
    this engine's samples only).
    An output is owned by the engine whose active filters feed it; outputs no filter feeds are owned
-   unless bfhip_engine_set_output_active says otherwise (the host gives them to the process that mixes the other members of their physical channel, else to process 0).
+   unless bfhip_engine_set_output_active says otherwise (the host gives them to the process that
+   mixes the other members of their physical channel, else to process 0).
    Virtual outputs that share a physical channel must be owned together.  All before finalize. */
 int bfhip_engine_set_filter_active(bfhip_engine *e, int filter, int active);
 int bfhip_engine_set_output_active(bfhip_engine *e, int ch, int active);
