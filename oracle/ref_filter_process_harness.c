@@ -159,6 +159,11 @@ main(int argc, char *argv[])
     conf.blocking_io = true;
     conf.quiet = true;
     conf.n_processes = n_procs;
+    if (getenv("BFREF_POWERSAVE") != NULL) {
+        /* `powersave: true;` (1.0: exact zeros) or `powersave: <dB>;` (its linear value), bfconf.c:1549-1561 */
+        conf.powersave = true;
+        conf.analog_powersave = atof(getenv("BFREF_POWERSAVE"));
+    }
     conf.benchmark = getenv("BFREF_BENCHMARK") != NULL;     /* `benchmark: true;`: the stage table of bfrun.c:2035-2078 on stderr */
     if (!convolver_init(NULL, L, rs)) {
         return 2;

@@ -413,3 +413,59 @@ def test_reference_filter_process_with_shared_channels_delays_mutes_dither_subde
         assert many == fused and many_of == fused_of, (seed, n_proc, f_owner)
         ref_many, ref_many_of, _ = _run_host(EXE, tmp_path, "u%d" % n_proc, spec, blocks, c["events"], f_owner)
         assert ref_many == plain and ref_many_of == plain_of, (seed, n_proc, f_owner)
+
+
+@pytest.mark.parametrize("rs", [4, 8])
+@pytest.mark.parametrize("mode", ["exact", "floor"])
+def test_reference_filter_process_with_powersave(hip, tmp_path, rs, mode):
+    """`powersave:` through the reference's loop (test_silent, bfrun.c:721-771; silent windows get a zero
+    spectrum, :1541-1553; filters whose inputs have been silent for a whole filter length are skipped and
+    their output buffers zeroed, :1694-1770): inputs go silent, come back, hover around the floor, one
+    never carries anything.  Unpatched host, patched host, the engine and the oracle."""
+    L, N, I, O = 128, 4, 3, 2
+    rng = np.random.default_rng(300)
+    coeffs = [(cases.make_ir(rng, L * N, I), 1.0, 0) for _ in range(I * O)]
+    filters = [_f(in_ch=[i], out_ch=[o], coeff=o * I + i, delayblocks=i % 2) for o in range(O) for i in range(I)]
+    filters.append(_f(in_ch=[0, 1], in_scale=[0.5, 0.5], out_ch=[0], coeff=0))
+    ofmt = "FLOAT_LE" if rs == 4 else "FLOAT64_LE"
+    spec = dict(L=L, N=N, rs=rs, n_in=I, n_out=O, infmt="S16_LE", outfmt=ofmt, coeffs=coeffs, filters=filters)
+    thr = 1.0 if mode == "exact" else 10 ** (-50 / 20)
+    amps = [3000, 3000, 0, 0, 0, 0, 0, 0, 40, 40, 200, 0, 3000, 0, 0, 0, 0, 0, 0, 3000]
+    blocks = []
+    for a in amps:
+        x = np.zeros((L, I), np.int16)
+        x[:, 0] = (rng.standard_normal(L) * a).astype(np.int16)
+        x[:, 1] = (rng.standard_normal(L) * (a // 2)).astype(np.int16)
+        blocks.append(x)
+    env = {"BFREF_POWERSAVE": repr(thr)}
+    plain, _, _ = _run_host(EXE, tmp_path, "plain", spec, blocks, {}, env=env)
+    fused, _, _ = _run_host(EXE_PATCHED, tmp_path, "fused", spec, blocks, {}, env=env)
+    off, _, _ = _run_host(EXE, tmp_path, "off", spec, blocks, {})
+    if mode == "exact":
+        assert plain == off                      # the reference itself: `powersave: true` changes no sample
+    odt = np.float32 if rs == 4 else np.float64
+    ref = np.frombuffer(plain, odt).reshape(len(amps), L, O).astype(np.float64)
+    pat = np.frombuffer(fused, odt).reshape(len(amps), L, O).astype(np.float64)
+
+    def mk(cls):
+        e = cls(L, N, rs, I, O)
+        e.set_interleaved(0, "S16_LE")
+        e.set_interleaved(1, ofmt)
+        e.set_powersave(thr)
+        for t, s_, nb in coeffs:
+            e.add_coeff(t, s_, nb)
+        for f in filters:
+            e.add_filter(**f)
+        if hasattr(e, "finalize"):
+            e.finalize()
+        return e
+    ge, oe = mk(hip.Engine), mk(bo.Engine)
+    scale = float(np.abs(ref).max())
+    tol = (3e-5 if rs == 4 else 1e-11) * scale
+    for b, blk in enumerate(blocks):
+        gs, g = ge.block(blk)
+        os_, o = oe.block(blk)
+        assert gs == os_ == 0
+        for who, arr in (("patched host", pat[b]), ("fused engine", np.frombuffer(g.tobytes(), odt).reshape(L, O)),
+                         ("oracle", np.frombuffer(o.tobytes(), odt).reshape(L, O))):
+            assert np.abs(arr.astype(np.float64) - ref[b]).max() <= tol, (who, b)
