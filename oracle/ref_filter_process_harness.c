@@ -102,7 +102,9 @@ main(int argc, char *argv[])
     char tok = 0;
     int ext, n_phys[2], sdf_length = -1;
     int32_t *x_v2p[2] = { NULL, NULL }, *x_delay[2], *x_maxdelay[2], *x_mute[2], *x_subdelay[2], *x_dither = NULL;
-    double sdf_beta = 9.0;
+    double sdf_beta = 9.0, *x_scale;
+    uint8_t **x_taps;
+    int *x_ntaps;
 
     if (argc != 3 || (f = fopen(argv[1], "rb")) == NULL) {
         fprintf(stderr, "usage: ref_filter_process spec out.raw\n");
@@ -260,13 +262,17 @@ main(int argc, char *argv[])
     conf.coeffs = emalloc(n_coeffs * sizeof(struct bfcoeff));
     conf.coeffs_data = emalloc(n_coeffs * sizeof(void **));
     memset(conf.coeffs, 0, n_coeffs * sizeof(struct bfcoeff));
+    x_taps = emalloc((n_coeffs + 1) * sizeof(uint8_t *));
+    x_ntaps = emalloc((n_coeffs + 1) * sizeof(int));
+    x_scale = emalloc((n_coeffs + 1) * sizeof(double));
     for (c = 0; c < n_coeffs; c++) {
         int n_taps = rd32(f), blocks = rd32(f);
         double scale;
-        uint8_t *taps, *zbuf;
+        uint8_t *taps, *zbuf, *dest = NULL;
         rd(f, &scale, 8);
         taps = emalloc((size_t)n_taps * rs + 1);
         rd(f, taps, (size_t)n_taps * rs);
+        x_taps[c] = taps; x_ntaps[c] = n_taps; x_scale[c] = scale;
         if (blocks <= 0) {
             blocks = (n_taps + L - 1) / L;
         }
@@ -274,14 +280,21 @@ main(int argc, char *argv[])
         memset(zbuf, 0, (size_t)L * rs);
         conf.coeffs[c].intname = c;
         conf.coeffs[c].n_blocks = blocks;
+        conf.coeffs[c].is_shared = getenv("BFREF_SHARED_COEFFS") != NULL;      /* `shared_mem: true;` */
+        if (conf.coeffs[c].is_shared) {
+            dest = shared_zero((size_t)2 * blocks * L * rs);                     /* bfconf.c:1983-1989 */
+        }
         conf.coeffs_data[c] = emalloc(blocks * sizeof(void *));
         for (n = 0; n < blocks; n++) {
             if (n * L > n_taps) {
-                conf.coeffs_data[c][n] = convolver_coeffs2cbuf(zbuf, L, scale, NULL);
+                conf.coeffs_data[c][n] = convolver_coeffs2cbuf(zbuf, L, scale, dest);
             } else if ((n + 1) * L > n_taps) {
-                conf.coeffs_data[c][n] = convolver_coeffs2cbuf(&taps[(size_t)n * L * rs], n_taps - n * L, scale, NULL);
+                conf.coeffs_data[c][n] = convolver_coeffs2cbuf(&taps[(size_t)n * L * rs], n_taps - n * L, scale, dest);
             } else {
-                conf.coeffs_data[c][n] = convolver_coeffs2cbuf(&taps[(size_t)n * L * rs], L, scale, NULL);
+                conf.coeffs_data[c][n] = convolver_coeffs2cbuf(&taps[(size_t)n * L * rs], L, scale, dest);
+            }
+            if (dest != NULL) {
+                dest += (size_t)2 * L * rs;
             }
             if (conf.coeffs_data[c][n] == NULL) {
                 fprintf(stderr, "ref_filter_process: coefficient set %d rejected\n", c);
@@ -491,7 +504,29 @@ main(int argc, char *argv[])
                     icomm->delay[ev[i].filter][ev[i].index] = (int)ev[i].value;
                 }
                 break;
-            default: icomm->subdelay[ev[i].filter][ev[i].index] = (int)ev[i].value; break;
+            case 7: icomm->subdelay[ev[i].filter][ev[i].index] = (int)ev[i].value; break;
+            default: {
+                /* what bflogic_eq does when it has rendered a new curve (render_equaliser, through
+                   bfaccess->convolver_coeffs2cbuf = convolver_runtime_coeffs2cbuf, bfrun.c:2305): a
+                   partition of a set in shared memory is rewritten in place while the filter process
+                   runs; filter = coefficient set, index = partition, value = gain on the set's own taps */
+                const int cs = ev[i].filter, b = ev[i].index;
+                const int len = x_ntaps[cs] - b * L;
+                if (conf.coeffs[cs].is_shared && b < conf.coeffs[cs].n_blocks && len > 0) {
+                    uint8_t *tmp = emalloc((size_t)L * rs);
+                    memset(tmp, 0, (size_t)L * rs);
+                    for (j = 0; j < (len > L ? L : len); j++) {
+                        if (rs == 4) {
+                            ((float *)tmp)[j] = (float)(((float *)x_taps[cs])[(size_t)b * L + j] * x_scale[cs] * ev[i].value);
+                        } else {
+                            ((double *)tmp)[j] = ((double *)x_taps[cs])[(size_t)b * L + j] * x_scale[cs] * ev[i].value;
+                        }
+                    }
+                    convolver_runtime_coeffs2cbuf(tmp, conf.coeffs_data[cs][b]);
+                    efree(tmp);
+                }
+                break;
+            }
             }
             icomm_mutex(0);
         }

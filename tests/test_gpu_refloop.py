@@ -59,8 +59,10 @@ def _write_spec(path, spec, blocks, events, f_owner=None):
                 evs.append((b, 5, ev[1], ev[2], float(ev[3])))
             elif ev[0] == "delay":                      # ("delay", io, virtual channel, samples)
                 evs.append((b, 6, ev[1], ev[2], float(ev[3])))
-            else:                                       # ("subdelay", io, virtual channel, slots)
+            elif ev[0] == "subdelay":                   # ("subdelay", io, virtual channel, slots)
                 evs.append((b, 7, ev[1], ev[2], float(ev[3])))
+            else:                                       # ("rewrite", coefficient set, partition, gain)
+                evs.append((b, 8, ev[1], ev[2], float(ev[3])))
     with open(path, "wb") as f:
         n_procs = 1 + (max(f_owner) if f_owner else 0)
         ch = spec.get("channels")
@@ -469,3 +471,49 @@ def test_reference_filter_process_with_powersave(hip, tmp_path, rs, mode):
         for who, arr in (("patched host", pat[b]), ("fused engine", np.frombuffer(g.tobytes(), odt).reshape(L, O)),
                          ("oracle", np.frombuffer(o.tobytes(), odt).reshape(L, O))):
             assert np.abs(arr.astype(np.float64) - ref[b]).max() <= tol, (who, b)
+
+
+@pytest.mark.parametrize("rs", [4, 8])
+def test_coefficient_partitions_rewritten_in_shared_memory_while_the_host_runs(hip, tmp_path, rs):
+    """`shared_mem: true;` coefficient sets rewritten in place by another process while the filter
+    process runs -- what bflogic_eq does after rendering a curve (convolver_runtime_coeffs2cbuf through
+    bfaccess, bfrun.c:2305).  The unpatched host reads the partition from shared memory in the next
+    block; the patched host registered the set BFHIP_COEFF_WATCH and has to notice by itself, in the
+    same block.  Against the engine driven directly (bfhip_engine_update_coeff_block)."""
+    L, N, I, O = 256, 4, 2, 2
+    rng = np.random.default_rng(17)
+    dt = np.float32 if rs == 4 else np.float64
+    taps = [cases.make_ir(rng, L * N, I).astype(dt) for _ in range(3)]
+    scales = [1.0, -0.5, 2.0]
+    coeffs = [(t, sc, 0) for t, sc in zip(taps, scales)]
+    filters = [_f(in_ch=[0], out_ch=[0], coeff=0), _f(in_ch=[1], out_ch=[1], coeff=1), _f(in_ch=[0, 1], in_scale=[0.5, -0.5], out_ch=[1], coeff=2),
+               _f(in_ch=[1], out_ch=[0], coeff=0, delayblocks=1)]
+    ofmt = "FLOAT_LE" if rs == 4 else "FLOAT64_LE"
+    spec = dict(L=L, N=N, rs=rs, n_in=I, n_out=O, infmt="S24_4LE", outfmt=ofmt, coeffs=coeffs, filters=filters)
+    events = {3: [("rewrite", 0, 1, 0.25)], 5: [("rewrite", 2, 0, -1.5), ("rewrite", 2, 3, 0.0)], 6: [("rewrite", 0, 1, 1.0)],
+              9: [("rewrite", 1, 2, 3.0), ("coeff", 1, 2)]}
+    blocks = cases.raw_blocks(8, 14, L, I, "S24_4LE", amplitude=0.2)
+    env = {"BFREF_SHARED_COEFFS": "1"}
+    plain, _, _ = _run_host(EXE, tmp_path, "plain", spec, blocks, events, env=env)
+    fused, _, _ = _run_host(EXE_PATCHED, tmp_path, "fused", spec, blocks, events, env=env)
+    still, _, _ = _run_host(EXE, tmp_path, "still", spec, blocks, {9: [("coeff", 1, 2)]}, env=env)
+    assert plain != still                        # the rewrites are audible
+    # two filter processes, every set registered lazily and watched in both: the same bytes
+    two, _, _ = _run_host(EXE_PATCHED, tmp_path, "fused2", spec, blocks, events, [0, 1, 1, 0], env=env)
+    assert two == fused
+    ref = np.frombuffer(plain, dt).reshape(len(blocks), L, O).astype(np.float64)
+    pat = np.frombuffer(fused, dt).reshape(len(blocks), L, O).astype(np.float64)
+    ge = cases.build(hip.Engine, spec)
+    tol = (3e-5 if rs == 4 else 1e-11) * float(np.abs(ref).max())
+    for b, blk in enumerate(blocks):
+        for ev in events.get(b, []):
+            if ev[0] == "rewrite":
+                _, cs, part, gain = ev
+                ge.update_coeff_block(cs, part, (taps[cs][part * L:(part + 1) * L].astype(np.float64) * scales[cs] * gain).astype(dt))
+            else:
+                ge.set_coeff(ev[1], ev[2])
+        st, g = ge.block(blk)
+        assert st == 0
+        eng = np.frombuffer(g.tobytes(), dt).reshape(L, O).astype(np.float64)
+        assert np.abs(pat[b] - ref[b]).max() <= tol, ("patched host", b, float(np.abs(pat[b] - ref[b]).max()))
+        assert np.abs(eng - ref[b]).max() <= tol, ("engine", b)
