@@ -358,6 +358,7 @@ struct bfhip_engine {
     void *d_entries = nullptr;
     size_t entries_cap = 0;
     ChunkRange *d_chunks = nullptr;
+    bool zp_is_sum = false;            // chunk 0 of the last block's partial-sum buffer holds the sum over all chunks (launch_sum in place)
     size_t chunks_cap = 0;
     uint8_t *d_rawin = nullptr, *d_rawout = nullptr;
     size_t raw_bytes[2] = {0, 0};
@@ -782,6 +783,7 @@ void launch_mac(bfhip_engine *e, void *Zp, hipError_t *err) {
 template <typename T>
 void launch_mac2(bfhip_engine *e, void *Zp0, void *Zp1, hipError_t *err) {
     const int n_tc = e->n_tiles * e->n_chunks;
+    e->zp_is_sum = false;
     const int grid = ((n_tc + 7) / 8) * e->n_groups * 8;
     hipLaunchKernelGGL((mac_xbar2_kernel<T, true>), dim3(grid), dim3(e->mac_threads), 0, e->ls,
                        (const MacEntry<T> *)e->d_entries, (const ChunkRange *)e->d_chunks, (c2<T> *)Zp0, (c2<T> *)Zp1,
@@ -796,6 +798,7 @@ void launch_sum(bfhip_engine *e, const void *Zp, void *Z, hipError_t *err) {
     const int grid = (int)((n_valid + 255) / 256);
     hipLaunchKernelGGL(sum_partials_kernel<T>, dim3(grid), dim3(256), 0, e->ls,
                        (const c2<T> *)Zp, (c2<T> *)Z, n_per_chunk, n_valid, e->n_chunks);
+    if (Z == Zp) e->zp_is_sum = true;
     *err = hipGetLastError();
 }
 
@@ -1896,6 +1899,7 @@ int do_levels(bfhip_engine *e) {
 
 int do_mac(bfhip_engine *e, void *Zp) {
     hipError_t err = hipSuccess;
+    e->zp_is_sum = false;
     if (e->rs == 4) launch_mac<float>(e, Zp, &err); else launch_mac<double>(e, Zp, &err);
     if (err != hipSuccess) return fail(BFHIP_EHIP, "mac launch: %s", hipGetErrorString(err));
     return BFHIP_OK;
@@ -3954,7 +3958,7 @@ int bfhip_engine_read_output_spectrum(bfhip_engine *e, int ch, void *dst) {
     const size_t row = (size_t)e->L * e->csize();
     std::vector<unsigned char> tmp(row);
     memset(dst, 0, row);
-    for (int c = 0; c < e->n_chunks; c++) {
+    for (int c = 0; c < (e->zp_is_sum ? 1 : e->n_chunks); c++) {
         const unsigned char *zp = (const unsigned char *)(((e->pipelined || e->defer_out) && e->d_Zp2 && ((e->blocks_done - 1) & 1)) ? e->d_Zp2 : e->d_Zp);
         if (e->pipe2) {
             const int zi = (int)((e->blocks_done - 1) % 3ull);

@@ -214,8 +214,9 @@ int bfhip_engine_add_filter(bfhip_engine *e,
    run inactive.  The engine plans for the whole configuration (output groups, entry order, chunk
    boundaries: every output is summed in exactly the order a single engine would use, so the
    outputs are bit-identical to the one-process run), launches the work of its own filters only,
-   transforms every input itself (no exchange between the processes: the two
-   synch_filter_processes barriers of bfrun.c:1563, 1873 stay as they are), and converts and
+   transforms every input itself (no exchange between the processes; of the two
+   synch_filter_processes barriers of bfrun.c:1563, 1873 the host keeps one per period, which paces
+   the processes on their shared wake pipe), and converts and
    writes only the outputs it owns: in the raw output buffer the processes share, and in the
    overflow array, everything else is left untouched -- by the device entry points (the output
    pass skips foreign channels) and by the host ones (bfhip_engine_block, bfhip_engine_rt_wait copy

@@ -531,6 +531,21 @@ main(int argc, char *argv[])
             icomm_mutex(0);
         }
         memcpy(inbuf[curbuf], rawin + (size_t)k * in_bytes, in_bytes);
+        /* BFREF_STALL_PROC0: filter process 0 is held while the period's tokens go out and the other
+           processes run -- all of them wake on the SAME pipe (bfrun.c:2480-2616), and what keeps a
+           fast one from taking process 0's token is a synch_filter_processes() barrier */
+        if (getenv("BFREF_STALL_PROC0") != NULL && n_procs > 1) {
+            kill(pids[0], SIGSTOP);
+            if (!writefd(in_pipe[1], toks, n_procs)) {
+                return 1;
+            }
+            usleep((useconds_t)atoi(getenv("BFREF_STALL_PROC0")));      /* the stall, in microseconds */
+            kill(pids[0], SIGCONT);
+            if (!readfd(out_pipe[0], toks, n_procs)) {
+                fprintf(stderr, "ref_filter_process: a filter process died in block %d\n", k);
+                return 1;
+            }
+        } else
         if (!writefd(in_pipe[1], toks, n_procs) || !readfd(out_pipe[0], toks, n_procs)) {
             fprintf(stderr, "ref_filter_process: a filter process died in block %d\n", k);
             return 1;

@@ -517,6 +517,24 @@ def test_fixed_delays_beside_a_subsample_filter_stay_inside_their_buffers(hip):
     assert int(np.argmax(np.abs(y))) == 5 + (700 + half) + (20 + half) and abs(y.max() - 1.0) < 1e-5
 
 
+def test_output_spectrum_reader_with_many_partial_sums(hip, monkeypatch):
+    """bfhip_engine_read_output_spectrum (debug / multi-GPU rehearsals): with more than two chunks of
+    partial sums the engine adds them up in place before the output pass -- the reader must not add
+    the other chunks on top again"""
+    L, N, I, O = 1024, 8, 2, 2
+    blocks = cases.raw_blocks(4, N + 3, L, I, "S24_4LE")
+
+    def run(target):
+        monkeypatch.setenv("BFHIP_MAC_TARGET_WGS", str(target))
+        e, _ = cases.crossbar(hip.Engine, L, N, 4, I, O, "S24_4LE", "FLOAT_LE")
+        for blk in blocks:
+            e.block(blk)
+        return np.stack([e.output_spectrum(o) for o in range(O)])
+    few, many = run(2), run(64)              # 2 tiles x 1 chunk, 2 tiles x 32 chunks
+    scale = float(np.abs(few).max())
+    assert scale > 0 and float(np.abs(few - many).max()) <= 1e-5 * scale
+
+
 def test_prewarm_changes_cost_not_results(hip):
     """bfhip_engine_prewarm: rings declared full of silence; outputs identical to a cold start,
     including for a ring depth that is not a power of two (unsigned wrap of blockcounter - p)"""

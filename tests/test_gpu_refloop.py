@@ -517,3 +517,24 @@ def test_coefficient_partitions_rewritten_in_shared_memory_while_the_host_runs(h
         eng = np.frombuffer(g.tobytes(), dt).reshape(L, O).astype(np.float64)
         assert np.abs(pat[b] - ref[b]).max() <= tol, ("patched host", b, float(np.abs(pat[b] - ref[b]).max()))
         assert np.abs(eng - ref[b]).max() <= tol, ("engine", b)
+
+
+def test_filter_processes_keep_step_on_their_shared_wake_pipe(hip, tmp_path):
+    """All filter processes are woken through ONE pipe, n_processes tokens per period
+    (bfrun.c:2480-2616); in the reference a synch_filter_processes() barrier keeps a fast process from
+    taking a second token of the same period.  The fused path needs no data from the other processes,
+    but it needs that barrier: with process 0 held back while the tokens go out (BFREF_STALL_PROC0), a
+    host without it lets another process run process 0's period on a buffer nobody has filled yet.
+    (Found by a soak: one three-process run in some thousand wrote a wrong block.)"""
+    L, N, I, O = 256, 3, 3, 3
+    rng = np.random.default_rng(3)
+    spec = dict(L=L, N=N, rs=4, n_in=I, n_out=O, infmt="S24_4LE", outfmt="S24_4LE",
+                coeffs=[(cases.make_ir(rng, L * N, I), 1.0, 0) for _ in range(3)],
+                filters=[_f(in_ch=[i], out_ch=[o], coeff=(i + o) % 3) for o in range(O) for i in range(I)])
+    blocks = cases.raw_blocks(1, 32, L, I, "S24_4LE", amplitude=0.2)     # (the first periods are slow ones: set-up, graph capture)
+    f_owner = [f["out_ch"][0] for f in spec["filters"]]          # process k mixes output k
+    one, one_of, _ = _run_host(EXE_PATCHED, tmp_path, "one", spec, blocks, {})
+    for exe, tag in ((EXE_PATCHED, "patched"), (EXE, "plain")):
+        want = one if exe == EXE_PATCHED else _run_host(EXE, tmp_path, "plain1", spec, blocks, {})[0]
+        got, _, _ = _run_host(exe, tmp_path, tag + "3", spec, blocks, {}, f_owner, env={"BFREF_STALL_PROC0": "40000"})     # 40 ms a period: many periods of the others, also on a shared GPU
+        assert got == want, tag

@@ -429,6 +429,12 @@ SETUP_CALL = r'''#ifdef BF_HAVE_BFHIP
 
 BLOCK_CALL = r'''#ifdef BF_HAVE_BFHIP
         if (bfhip_eng != NULL) {
+            /* No data passes between the processes here (every engine transforms all inputs and
+               mixes its own outputs), but ONE of the reference's two barriers (:1563, :1873) stays:
+               all filter processes are woken through the same pipe, n_processes tokens per
+               period, and only a barrier keeps a fast process from taking a second token of the
+               same period -- and with it a period the input process has not written yet. */
+            synch_filter_processes(filter_readfd, filter_writefd, process_index);
             bfhip_period(icomm_fctrl, icomm_ismuted, icomm_delay, icomm_subdelay,
                          inbuf[curbuf], outbuf[curbuf]);
             for (n = 0; n < n_filters; n++) {
