@@ -1796,10 +1796,13 @@ int do_vout(bfhip_engine *e, void *rawout_dev) {
             if (e->dither_channels[d] == g[0] && e->dither_late[d]) j.dither = 1;
         for (int v : g) {
             VOutMember m;
-            m.channel = v; m.muted = e->vmuted[1][v]; m.ops_off = (int)ops.size();
+            // a 1:1 output is here for its sub-sample filter only: its delay and mute are dai.c's business
+            // on the raw buffer (bfrun.c:1926-1936 converts it whatever icomm says)
+            const bool shared = g.size() > 1;
+            m.channel = v; m.muted = shared ? e->vmuted[1][v] : 0; m.ops_off = (int)ops.size();
             uint8_t *row = (uint8_t *)e->d_timeout + (size_t)v * e->L * e->rs;
-            const int extra = (side_uses_subdelay(e, 1) && e->sd_slot[1][v] < 0 && e->n_vpp[1][e->v2p[1][v]] > 1) ? e->sdf_length : 0;
-            e->vline[1][v].update(row, e->vdelay[1][v] + extra, ops);        // always advanced (:1948)
+            const int extra = (side_uses_subdelay(e, 1) && e->sd_slot[1][v] < 0 && shared) ? e->sdf_length : 0;
+            e->vline[1][v].update(row, shared ? e->vdelay[1][v] + extra : 0, ops);        // always advanced (:1948)
             m.n_ops = (int)ops.size() - m.ops_off;
             mem.push_back(m);
         }
