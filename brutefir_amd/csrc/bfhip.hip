@@ -1707,6 +1707,9 @@ int do_subdelay_t(bfhip_engine *e, int io, const void *rawin_dev) {
     for (int v = 0; v < e->n_ch[io]; v++) {
         const int slot = e->sd_slot[io][v];
         if (slot < 0) continue;
+        // an output another engine converts is not filtered here: nobody mixes or quantises it in this
+        // engine, and an engine that owns no such output at all has no time-sample buffer either
+        if (io == 1 && (!e->out_active[v] || e->d_timeout == nullptr)) continue;
         SdJob<T> j;
         memset(&j, 0, sizeof(j));
         const int sd = e->subdelay[io][v];

@@ -1043,18 +1043,20 @@ bfo_engine_block(bfo_engine *e, const void *rawin, void *rawout)
                samples, integer delay or mute applied here (dai.c does it for 1:1 channels) */
             bfo_format cf = *bf;
             cf.sample_spacing = 1; cf.byte_offset = 0;
+            /* channels without a sub-sample filter are delayed by its integer part
+               (bfrun.c:1152-1162, 1512-1516) */
+            const int extra = (side_uses_subdelay(e, 0) && e->subdelay[0][n] == -100) ? e->sdf_length : 0;
+            if (e->db[0][n] == NULL) {
+                /* the delay buffer exists from the start, with the delay configured then (bfrun.c:1128-1166),
+                   muted or not -- not from the first block the channel is heard in */
+                int d0, m0;
+                vdelay_limits(e->delay[0][n], e->maxdelay[0][n], extra, &d0, &m0);
+                e->db[0][n] = bfo_delay_new(e->L, d0, m0, bf->bytes);
+            }
             if (!e->muted[0][n]) {
                 const uint8_t *src = (const uint8_t *)rawin + bf->byte_offset;
                 const size_t st = (size_t)bf->sample_spacing * bf->bytes;
                 for (i = 0; i < e->L; i++) memcpy((uint8_t *)e->incopy + (size_t)i * bf->bytes, src + i * st, bf->bytes);
-                /* channels without a sub-sample filter are delayed by its integer part
-                   (bfrun.c:1152-1162, 1512-1516) */
-                const int extra = (side_uses_subdelay(e, 0) && e->subdelay[0][n] == -100) ? e->sdf_length : 0;
-                if (e->db[0][n] == NULL) {
-                    int d0, m0;
-                    vdelay_limits(e->delay[0][n], e->maxdelay[0][n], extra, &d0, &m0);
-                    e->db[0][n] = bfo_delay_new(e->L, d0, m0, bf->bytes);
-                }
                 bfo_delay_update(e->db[0][n], e->incopy, e->delay[0][n] + extra);
             } else {
                 memset(e->incopy, 0, (size_t)e->L * bf->bytes);

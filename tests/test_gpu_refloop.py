@@ -317,6 +317,16 @@ def _channel_case(seed):
                 shared = c["maps"][io].count(c["maps"][io][v]) > 1
                 if shared and c["subdelay"][io][v] == UNDEF_SUBDELAY and c["maxd"][io][v] < 0:
                     c["maxd"][io][v] = 1200
+        # run-time changes of the sub-sample value on channels that have a filter (what bfaccess->set_subdelay
+        # leaves in icomm->subdelay, bfrun.c:520-541; +-100 and beyond = "no filter this period", delay.c:438-442)
+        for _ in range(int(rng.integers(0, 5))):
+            io = int(rng.integers(0, 2))
+            with_filter = [v for v in range(c["nv"][io]) if c["subdelay"][io][v] != UNDEF_SUBDELAY]
+            if with_filter:
+                b = int(rng.integers(1, c["n_blocks"]))
+                c["events"].setdefault(b, []).append(("subdelay", io, int(rng.choice(with_filter)), int(rng.integers(-99, 100))))
+    # channels muted from the start (`mute: true` in the device section -> bfconf->mute -> icomm->ismuted, bfrun.c:2204-2208)
+    c["mute"] = [[int(rng.random() < 0.12) for _ in range(c["nv"][io])] for io in range(2)]
     return c
 
 
@@ -340,6 +350,8 @@ def _channel_engine(cls, c):
         for v in range(c["nv"][io]):
             e.set_delay(io, v, c["delay"][io][v])
             e.set_maxdelay(io, v, c["maxd"][io][v])
+            if c["mute"][io][v]:
+                e.set_mute(io, v, 1)
             if c["sdf_length"] > 0 and c["subdelay"][io][v] != UNDEF_SUBDELAY:
                 e.set_subdelay(io, v, c["subdelay"][io][v])
     for f in c["filters"]:
@@ -364,7 +376,7 @@ def test_reference_filter_process_with_shared_channels_delays_mutes_dither_subde
     n_phys_in, n_phys_out = max(c["maps"][0]) + 1, max(c["maps"][1]) + 1
     spec = dict(L=c["L"], N=c["N"], rs=c["rs"], n_in=c["nv"][0], n_out=c["nv"][1], infmt=c["infmt"], outfmt=c["outfmt"],
                 coeffs=[(h, 1.0, 0) for h in c["coeffs"]], filters=[_f(**f) for f in c["filters"]],
-                channels=dict(maps=c["maps"], delay=c["delay"], maxdelay=c["maxd"], mute=[[0] * c["nv"][0], [0] * c["nv"][1]],
+                channels=dict(maps=c["maps"], delay=c["delay"], maxdelay=c["maxd"], mute=c["mute"],
                               subdelay=c["subdelay"], dither=c["dither"], sdf_length=c["sdf_length"]))
     blocks = cases.raw_blocks(seed, c["n_blocks"], c["L"], n_phys_in, c["infmt"], amplitude=0.2)
     plain, plain_of, _ = _run_host(EXE, tmp_path, "plain", spec, blocks, c["events"])
@@ -378,7 +390,7 @@ def test_reference_filter_process_with_shared_channels_delays_mutes_dither_subde
     for b, blk in enumerate(blocks):
         for eng in (ge, oe):
             for kind, io, v, val in c["events"].get(b, []):
-                (eng.set_delay if kind == "delay" else eng.set_mute)(io, v, val)
+                {"delay": eng.set_delay, "mute": eng.set_mute, "subdelay": eng.set_subdelay}[kind](io, v, val)
         gs, g = ge.block(blk)
         os_, o = oe.block(blk)
         assert gs == os_ == 0, (seed, b)

@@ -190,6 +190,47 @@ def test_shared_physical_outputs_dither_and_subdelay_in_shards(hip):
         assert (got.n_overflows, got.intlargest, got.largest) == (want.n_overflows, want.intlargest, want.largest)
 
 
+def test_a_shard_without_any_filtered_or_shared_output_of_its_own(hip):
+    """every output with a sub-sample filter and every shared physical output belongs to the OTHER engine:
+    this one has no time-sample buffer and nothing to filter behind the inverse transforms (it once
+    launched the sub-sample filters of the foreign outputs on that missing buffer: a memory fault on
+    the GPU, found by tests/test_gpu_refloop.py's soak through the patched host)"""
+    L, N = 256, 2
+    rng = np.random.default_rng(5)
+    taps = [cases.make_ir(rng, L * N, 2).astype(np.float64) for _ in range(3)]
+
+    def build(k):
+        e = hip.Engine(L, N, 8, 2, 6)
+        e.map_channels(0, [0, 0])
+        e.map_channels(1, [2, 0, 2, 0, 1, 2])           # physical 1 <- virtual 4 alone; 0 and 2 are shared
+        e.set_interleaved_phys(0, "S16_LE", 1)
+        e.set_interleaved_phys(1, "S24_4LE", 3)
+        e.enable_subdelay(7, 9.0)
+        e.set_subdelay(1, 0, -51)
+        e.set_subdelay(1, 3, -72)
+        for v, (d, md) in enumerate([(0, 0), (458, 1200), (866, 900), (165, 300), (15, 40), (0, 0)]):
+            e.set_maxdelay(1, v, md); e.set_delay(1, v, d)
+        for t in taps:
+            e.add_coeff(t)
+        e.add_filter(in_ch=[0], out_ch=[2, 5], coeff=1)
+        e.add_filter(in_ch=[1], out_ch=[4], coeff=2)
+        if k is not None:
+            e.set_filter_active(0, k == 0)
+            e.set_filter_active(1, k == 1)
+            for v in range(6):
+                e.set_output_active(v, (k == 1) == (v == 4))      # engine 1: the 1:1 output only
+        e.finalize()
+        return e
+    whole, shards = build(None), [build(0), build(1)]
+    for b, blk in enumerate(cases.raw_blocks(7, 8, L, 1, "S16_LE", amplitude=0.3)):
+        _, w = whole.block(blk)
+        shared = np.full(w.size, 0x5A, np.uint8)
+        for s_ in shards:
+            st, _ = s_.block(blk, out=shared)
+            assert st == 0
+        assert np.array_equal(shared, w), b
+
+
 def test_shard_rules_are_checked_at_finalize(hip):
     L, N = 64, 2
     taps = np.ones(L, np.float32)
