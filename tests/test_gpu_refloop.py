@@ -205,7 +205,7 @@ def test_reference_filter_process_on_the_reference_s_own_configurations(hip, tmp
 def _run_host(exe, tmp_path, tag, spec, blocks, events, f_owner=None, env=None):
     _write_spec(tmp_path / ("spec_%s.bin" % tag), spec, blocks, events, f_owner)
     out = tmp_path / ("out_%s.raw" % tag)
-    r = subprocess.run([exe, str(tmp_path / ("spec_%s.bin" % tag)), str(out)], capture_output=True, text=True, timeout=240,
+    r = subprocess.run([exe, str(tmp_path / ("spec_%s.bin" % tag)), str(out)], capture_output=True, text=True, timeout=90,
                        env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, (tag, r.stdout[-500:], r.stderr[-1500:])
     return open(out, "rb").read(), [ln for ln in r.stdout.splitlines() if ln.startswith("output ")], r.stderr
