@@ -550,3 +550,128 @@ def test_filter_processes_keep_step_on_their_shared_wake_pipe(hip, tmp_path):
         want = one if exe == EXE_PATCHED else _run_host(EXE, tmp_path, "plain1", spec, blocks, {})[0]
         got, _, _ = _run_host(exe, tmp_path, tag + "3", spec, blocks, {}, f_owner, env={"BFREF_STALL_PROC0": "40000"})     # 40 ms a period: many periods of the others, also on a shared GPU
         assert got == want, tag
+
+
+def _combined_case(seed):
+    """a random filter NETWORK (cascades, cross-fades, delayblocks, run-time control: test_gpu_fuzz._network)
+    on top of random channel maps (N:1 both sides, integer delays, mutes, and for some seeds dither or
+    sub-sample delays): the two generators the other tests use apart, together"""
+    spec, n_blocks, events = fuzz._network(seed + 20000)
+    rng = np.random.default_rng(seed + 555)
+    nv = [spec["n_in"], spec["n_out"]]
+    maps = []
+    for io in range(2):
+        n_phys = int(rng.integers(1, nv[io] + 1))
+        v2p = list(range(n_phys)) + [int(rng.integers(0, n_phys)) for _ in range(nv[io] - n_phys)]     # every physical channel used
+        maps.append([int(x) for x in rng.permutation(v2p)])
+    maxd = [[int(rng.choice([0, 40, 300, 900, -1])) for _ in range(nv[io])] for io in range(2)]
+    lim = lambda md: 1200 if md < 0 else md        # noqa: E731
+    delay = [[int(rng.integers(0, lim(maxd[io][v]) + 1)) for v in range(nv[io])] for io in range(2)]
+    outfmt = ["S16_LE", "S24_4LE", cases_float(spec["rs"])][seed % 3]
+    n_phys_out = max(maps[1]) + 1
+    dither = [int(rng.random() < 0.6) if outfmt == "S16_LE" else 0 for _ in range(n_phys_out)]
+    sdf_length, subdelay = -1, [[UNDEF_SUBDELAY] * nv[io] for io in range(2)]
+    if seed % 4 == 3:
+        sdf_length = int(rng.choice([3, 7, 15]))
+        for io in range(2):
+            for v in range(nv[io]):
+                if rng.random() < 0.4:
+                    subdelay[io][v] = int(rng.integers(-99, 100))
+        for io in range(2):                          # (see _channel_case: where the reference overruns its own buffer)
+            if any(sd != UNDEF_SUBDELAY for sd in subdelay[io]):
+                for v in range(nv[io]):
+                    if maps[io].count(maps[io][v]) > 1 and subdelay[io][v] == UNDEF_SUBDELAY and maxd[io][v] < 0:
+                        maxd[io][v] = 1200
+    ch_events = {}
+    for _ in range(int(rng.integers(0, 8))):
+        b = int(rng.integers(1, n_blocks))
+        io = int(rng.integers(0, 2))
+        v = int(rng.integers(0, nv[io]))
+        if rng.random() < 0.6:
+            ch_events.setdefault(b, []).append(("delay", io, v, int(rng.integers(0, lim(maxd[io][v]) + 1))))
+        else:
+            ch_events.setdefault(b, []).append(("mute", io, v, int(rng.integers(0, 2))))
+    mute = [[int(rng.random() < 0.1) for _ in range(nv[io])] for io in range(2)]
+    spec = dict(spec, outfmt=outfmt)
+    return dict(spec=spec, n_blocks=n_blocks, events=events, ch_events=ch_events, maps=maps, nv=nv, maxd=maxd, delay=delay,
+                dither=dither, sdf_length=sdf_length, subdelay=subdelay, mute=mute)
+
+
+def _combined_engine(cls, c):
+    spec = c["spec"]
+    e = cls(spec["L"], spec["N"], spec["rs"], spec["n_in"], spec["n_out"])
+    e.map_channels(0, c["maps"][0])
+    e.map_channels(1, c["maps"][1])
+    e.set_interleaved_phys(0, spec["infmt"], max(c["maps"][0]) + 1)
+    e.set_interleaved_phys(1, spec["outfmt"], max(c["maps"][1]) + 1)
+    if c["sdf_length"] > 0:
+        e.enable_subdelay(c["sdf_length"], 9.0)
+    if any(c["dither"]):
+        e.enable_dither([p for p, d in enumerate(c["dither"]) if d], 44100)
+    for taps, scale, nb in spec["coeffs"]:
+        e.add_coeff(taps, scale, nb)
+    for io in range(2):
+        for v in range(c["nv"][io]):
+            e.set_delay(io, v, c["delay"][io][v])
+            e.set_maxdelay(io, v, c["maxd"][io][v])
+            if c["mute"][io][v]:
+                e.set_mute(io, v, 1)
+            if c["sdf_length"] > 0 and c["subdelay"][io][v] != UNDEF_SUBDELAY:
+                e.set_subdelay(io, v, c["subdelay"][io][v])
+    for f in spec["filters"]:
+        e.add_filter(**f)
+    if hasattr(e, "finalize"):
+        e.finalize()
+    return e
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BFHIP_REFLOOP_SEEDS", "24"))))
+def test_reference_filter_process_on_random_networks_over_random_channel_maps(hip, tmp_path, seed):
+    """everything at once: filter networks with run-time control (cascades through convolve_eval,
+    cross-fades, coeff -1, delayblocks) over N:1 channel maps with delays, mutes, dither and sub-sample
+    delays.  The reference's loop (unpatched), the patched loop -- which takes the fused path or, where
+    bfhip_wanted() says so, the unfused one -- the engine driven directly and the oracle."""
+    for exe in (EXE, EXE_PATCHED):
+        if not os.path.exists(exe):
+            pytest.fail("%s is missing (built from the reference's bfrun.c in the build container)" % exe)
+    c = _combined_case(seed)
+    spec = c["spec"]
+    n_blocks, L = c["n_blocks"], spec["L"]
+    n_phys_in, n_phys_out = max(c["maps"][0]) + 1, max(c["maps"][1]) + 1
+    hspec = dict(spec, channels=dict(maps=c["maps"], delay=c["delay"], maxdelay=c["maxd"], mute=c["mute"],
+                                     subdelay=c["subdelay"], dither=c["dither"], sdf_length=c["sdf_length"]))
+    events = {b: list(c["events"].get(b, [])) + list(c["ch_events"].get(b, [])) for b in set(c["events"]) | set(c["ch_events"])}
+    blocks = cases.raw_blocks(seed, n_blocks, L, n_phys_in, spec["infmt"], amplitude=0.2)
+    plain, _, _ = _run_host(EXE, tmp_path, "plain", hspec, blocks, events)
+    fused, _, _ = _run_host(EXE_PATCHED, tmp_path, "fused", hspec, blocks, events)
+    odt = {"FLOAT_LE": np.float32, "FLOAT64_LE": np.float64, "S24_4LE": np.int32, "S16_LE": np.int16}[spec["outfmt"]]
+    ref = np.frombuffer(plain, odt).reshape(n_blocks, L, n_phys_out).astype(np.float64)
+    pat = np.frombuffer(fused, odt).reshape(n_blocks, L, n_phys_out).astype(np.float64)
+    ge, oe = _combined_engine(hip.Engine, c), _combined_engine(bo.Engine, c)
+    tol = 3e-5 if spec["rs"] == 4 else 1e-11
+    full = {"S16_LE": 32768.0, "S24_4LE": 8388608.0}.get(spec["outfmt"], 1.0)
+    scale = float(np.abs(ref).max())
+    for b, blk in enumerate(blocks):
+        for eng in (ge, oe):
+            fuzz._apply(eng, c["events"].get(b, []))
+            for kind, io, v, val in c["ch_events"].get(b, []):
+                {"delay": eng.set_delay, "mute": eng.set_mute}[kind](io, v, val)
+        gs, g = ge.block(blk)
+        os_, o = oe.block(blk)
+        assert gs == os_ == 0, (seed, b)
+        got = {"patched host": pat[b],
+               "fused engine": np.frombuffer(g.tobytes(), odt).reshape(L, n_phys_out).astype(np.float64),
+               "oracle": np.frombuffer(o.tobytes(), odt).reshape(L, n_phys_out).astype(np.float64)}
+        for who, arr in got.items():
+            for ch in range(n_phys_out):
+                want = ref[b][:, ch]
+                if full > 1.0:
+                    # integer outputs: the float tolerance in counts (a cross-fade block is three more float32
+                    # round trips), plus the rounding itself -- two counts on a dithered channel (error feedback)
+                    lvl = max(float(np.sqrt((want ** 2).mean())), 1e-3 * scale, fuzz.FLOOR * full)
+                    lim = (2.0 if c["dither"][ch] else 1.0) + 4 * tol * lvl * 4
+                    assert np.abs(arr[:, ch] - want).max() <= lim, (who, seed, b, ch, float(np.abs(arr[:, ch] - want).max()), lim)
+                else:
+                    lvl = max(float(np.sqrt((want ** 2).mean())), 1e-3 * scale, fuzz.FLOOR)
+                    err = float(np.sqrt(((arr[:, ch] - want) ** 2).mean()))
+                    assert err <= tol * lvl, (who, seed, b, ch, err, lvl)
