@@ -675,3 +675,14 @@ def test_reference_filter_process_on_random_networks_over_random_channel_maps(hi
                     lvl = max(float(np.sqrt((want ** 2).mean())), 1e-3 * scale, fuzz.FLOOR)
                     err = float(np.sqrt(((arr[:, ch] - want) ** 2).mean()))
                     assert err <= tol * lvl, (who, seed, b, ch, err, lvl)
+    # ... and the patched host with the filters dealt out over two and three filter processes (connected
+    # filters and the members of a shared physical output together): the bytes of its one-process run
+    from test_gpu_shards import _assign
+    by_phys = dict(spec, filters=[dict(f, out_ch=[c["maps"][1][o] for o in f["out_ch"]]) for f in spec["filters"]])
+    rng = np.random.default_rng(seed)
+    for n_proc in (2, 3):
+        f_owner, _ = _assign(by_phys, n_proc, rng)
+        if len(set(f_owner)) != n_proc:
+            continue
+        many, _, _ = _run_host(EXE_PATCHED, tmp_path, "p%d" % n_proc, hspec, blocks, events, f_owner)
+        assert many == fused, (seed, n_proc, f_owner)
