@@ -593,8 +593,16 @@ def _combined_case(seed):
             ch_events.setdefault(b, []).append(("mute", io, v, int(rng.integers(0, 2))))
     mute = [[int(rng.random() < 0.1) for _ in range(nv[io])] for io in range(2)]
     spec = dict(spec, outfmt=outfmt)
+    # `powersave: true;` (exact zeros) for every fifth case, with stretches of silence in the input.  It is
+    # meant to skip work, not to change samples (brutefir.html: "pause filtering when input is zero"), and in
+    # this engine it does not; the reference's zero-flag bookkeeping does in three corners (a
+    # run-time `delayblocks` change -- a burst of 0.5 on a 0.03 signal in seed 14; a cross-fading switch while
+    # some partitions are flagged silent -- crossfadebuf mixed in unwritten, "NaN or Inf" aborts; a silent
+    # member of a shared physical output behind a delayed one -- ocbuf[0] is delayed in place and still
+    # flagged zero, seed 109).  So these cases are held to the reference's run WITHOUT powersave.
+    powersave = 1.0 if seed % 5 == 4 else 0.0
     return dict(spec=spec, n_blocks=n_blocks, events=events, ch_events=ch_events, maps=maps, nv=nv, maxd=maxd, delay=delay,
-                dither=dither, sdf_length=sdf_length, subdelay=subdelay, mute=mute)
+                dither=dither, sdf_length=sdf_length, subdelay=subdelay, mute=mute, powersave=powersave)
 
 
 def _combined_engine(cls, c):
@@ -604,6 +612,8 @@ def _combined_engine(cls, c):
     e.map_channels(1, c["maps"][1])
     e.set_interleaved_phys(0, spec["infmt"], max(c["maps"][0]) + 1)
     e.set_interleaved_phys(1, spec["outfmt"], max(c["maps"][1]) + 1)
+    if c["powersave"]:
+        e.set_powersave(c["powersave"])
     if c["sdf_length"] > 0:
         e.enable_subdelay(c["sdf_length"], 9.0)
     if any(c["dither"]):
@@ -642,8 +652,19 @@ def test_reference_filter_process_on_random_networks_over_random_channel_maps(hi
                                      subdelay=c["subdelay"], dither=c["dither"], sdf_length=c["sdf_length"]))
     events = {b: list(c["events"].get(b, [])) + list(c["ch_events"].get(b, [])) for b in set(c["events"]) | set(c["ch_events"])}
     blocks = cases.raw_blocks(seed, n_blocks, L, n_phys_in, spec["infmt"], amplitude=0.2)
-    plain, _, _ = _run_host(EXE, tmp_path, "plain", hspec, blocks, events)
-    fused, _, _ = _run_host(EXE_PATCHED, tmp_path, "fused", hspec, blocks, events)
+    env = {}
+    if c["powersave"]:
+        env["BFREF_POWERSAVE"] = repr(c["powersave"])
+        prng = np.random.default_rng(seed + 99)
+        for blk in blocks:                               # stretches of silence and of near silence
+            for ch in range(n_phys_in):
+                u = prng.random()
+                if u < 0.3:
+                    blk[:, ch] = 0
+                elif u < 0.4 and not spec["infmt"].startswith("FLOAT"):
+                    blk[:, ch] = (blk[:, ch].astype(np.int64) >> 12).astype(blk.dtype)
+    plain, _, _ = _run_host(EXE, tmp_path, "plain", hspec, blocks, events)               # (without powersave: see _combined_case)
+    fused, _, _ = _run_host(EXE_PATCHED, tmp_path, "fused", hspec, blocks, events, env=env)
     odt = {"FLOAT_LE": np.float32, "FLOAT64_LE": np.float64, "S24_4LE": np.int32, "S16_LE": np.int16}[spec["outfmt"]]
     ref = np.frombuffer(plain, odt).reshape(n_blocks, L, n_phys_out).astype(np.float64)
     pat = np.frombuffer(fused, odt).reshape(n_blocks, L, n_phys_out).astype(np.float64)
@@ -684,5 +705,5 @@ def test_reference_filter_process_on_random_networks_over_random_channel_maps(hi
         f_owner, _ = _assign(by_phys, n_proc, rng)
         if len(set(f_owner)) != n_proc:
             continue
-        many, _, _ = _run_host(EXE_PATCHED, tmp_path, "p%d" % n_proc, hspec, blocks, events, f_owner)
+        many, _, _ = _run_host(EXE_PATCHED, tmp_path, "p%d" % n_proc, hspec, blocks, events, f_owner, env=env)
         assert many == fused, (seed, n_proc, f_owner)
