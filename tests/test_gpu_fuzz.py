@@ -23,10 +23,10 @@ FLOOR = 0.1 * 0.2           # a tenth of the input amplitude: the rounding noise
                             # loudest sample in the 2L window, not with what is left after delays and cancellation
 
 
-def _network(seed):
+def _network(seed, Ls=(64, 128, 256), max_n=9):
     rng = np.random.default_rng(1000 + seed)
-    L = int(rng.choice([64, 128, 256]))
-    N = int(rng.integers(1, 10))
+    L = int(rng.choice(list(Ls)))
+    N = int(rng.integers(1, max_n + 1))
     rs = int(rng.choice([4, 8]))
     n_in, n_out = int(rng.integers(1, 5)), int(rng.integers(1, 12))
     n_coeffs = int(rng.integers(1, 5))

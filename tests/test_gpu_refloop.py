@@ -385,6 +385,7 @@ def test_reference_filter_process_with_shared_channels_delays_mutes_dither_subde
     ref = np.frombuffer(plain, odt).reshape(c["n_blocks"], c["L"], n_phys_out).astype(np.float64)
     pat = np.frombuffer(fused, odt).reshape(c["n_blocks"], c["L"], n_phys_out).astype(np.float64)
     ge, oe = _channel_engine(hip.Engine, c), _channel_engine(bo.Engine, c)
+    undefined = _undefined_dither_samples(c["L"], c["rs"], sum(c["dither"]), c["n_blocks"]) if any(c["dither"]) else None
     tol = 3e-5 if c["rs"] == 4 else 1e-11
     scale = float(np.abs(ref).max())
     for b, blk in enumerate(blocks):
@@ -405,7 +406,11 @@ def test_reference_filter_process_with_shared_channels_delays_mutes_dither_subde
                 # each way on top of their own rounding
                 lim = 4.0 if c["outfmt"] == "S24_4LE" else 1.0
                 dith = np.asarray(c["dither"], bool)
-                d = np.abs(arr - ref[b]).max(axis=0)
+                dev = np.abs(arr - ref[b])
+                for k, pch in enumerate(np.nonzero(dith)[0]):         # (where the reference reads past its dither table)
+                    if undefined[k][b]:
+                        dev[sorted(undefined[k][b]), pch] = 0.0
+                d = dev.max(axis=0)
                 assert (d[~dith] <= lim).all() and (d[dith] <= 2.0).all(), (who, seed, b, d)
                 continue
             else:
@@ -556,7 +561,8 @@ def _combined_case(seed):
     """a random filter NETWORK (cascades, cross-fades, delayblocks, run-time control: test_gpu_fuzz._network)
     on top of random channel maps (N:1 both sides, integer delays, mutes, and for some seeds dither or
     sub-sample delays): the two generators the other tests use apart, together"""
-    spec, n_blocks, events = fuzz._network(seed + 20000)
+    # (every seventh case at the partition lengths of the wave-level transforms, fft_wave.h: 4096 by default)
+    spec, n_blocks, events = fuzz._network(seed + 20000, Ls=(4096, 8192), max_n=3) if seed % 7 == 6 else fuzz._network(seed + 20000)
     rng = np.random.default_rng(seed + 555)
     nv = [spec["n_in"], spec["n_out"]]
     maps = []
@@ -603,6 +609,34 @@ def _combined_case(seed):
     powersave = 1.0 if seed % 5 == 4 else 0.0
     return dict(spec=spec, n_blocks=n_blocks, events=events, ch_events=ch_events, maps=maps, nv=nv, maxd=maxd, delay=delay,
                 dither=dither, sdf_length=sdf_length, subdelay=subdelay, mute=mute, powersave=powersave)
+
+
+def _undefined_dither_samples(L, rs, n_dithered, n_blocks):
+    """The HP-TPDF quantiser looks its dither up at randmap[r[n] - r[n-1]], r int8: the index runs to +255,
+    the reference's table to +254 (dither.c:115-130) -- what it adds for 127 - (-128) is whatever lies
+    behind its allocation (this engine continues the table's formula).  One sample in 65536:
+    with partitions of thousands of samples some block of a run meets it.  The walk through the random
+    table is reproduced here (the oracle's table is bit-identical to dither.c's, tests/test_oracle_golden.py)
+    and those samples are named, per dithered channel (in the order of the dither list) and block -- with
+    the 31 behind each: the error feedback carries a stray value two samples on, and through as many clipped
+    samples as it takes to come back into range when the stray value was huge (seed 153: 7 samples)."""
+    ctx = bo.Ctx(L, rs)
+    if not ctx.dither_init(n_dithered, 44100):
+        return None
+    tab = ctx.dither_table().astype(np.int64)
+    ptr = [int(bo.lib().bfo_dither_randtab_ptr(ctx.h, k)) for k in range(n_dithered)]
+    bad = [[set() for _ in range(n_blocks)] for _ in range(n_dithered)]
+    for b in range(n_blocks):
+        for k in range(n_dithered):
+            p = ptr[k]
+            if p + L >= len(tab):                       # dither_preloop_real2int_hp_tpdf, dither.h:28-38
+                tab[0] = tab[p - 1]
+                p = 1
+            seg = tab[p - 1:p + L]
+            for i in np.nonzero(seg[1:] - seg[:-1] == 255)[0]:
+                bad[k][b].update(range(int(i), min(int(i) + 32, L)))
+            ptr[k] = p + L
+    return bad
 
 
 def _combined_engine(cls, c):
@@ -669,6 +703,8 @@ def test_reference_filter_process_on_random_networks_over_random_channel_maps(hi
     ref = np.frombuffer(plain, odt).reshape(n_blocks, L, n_phys_out).astype(np.float64)
     pat = np.frombuffer(fused, odt).reshape(n_blocks, L, n_phys_out).astype(np.float64)
     ge, oe = _combined_engine(hip.Engine, c), _combined_engine(bo.Engine, c)
+    dith_rank = {p: k for k, p in enumerate(p for p, d in enumerate(c["dither"]) if d)}
+    undefined = _undefined_dither_samples(L, spec["rs"], len(dith_rank), n_blocks) if dith_rank else None
     tol = 3e-5 if spec["rs"] == 4 else 1e-11
     full = {"S16_LE": 32768.0, "S24_4LE": 8388608.0}.get(spec["outfmt"], 1.0)
     scale = float(np.abs(ref).max())
@@ -691,7 +727,10 @@ def test_reference_filter_process_on_random_networks_over_random_channel_maps(hi
                     # round trips), plus the rounding itself -- two counts on a dithered channel (error feedback)
                     lvl = max(float(np.sqrt((want ** 2).mean())), 1e-3 * scale, fuzz.FLOOR * full)
                     lim = (2.0 if c["dither"][ch] else 1.0) + 4 * tol * lvl * 4
-                    assert np.abs(arr[:, ch] - want).max() <= lim, (who, seed, b, ch, float(np.abs(arr[:, ch] - want).max()), lim)
+                    dev = np.abs(arr[:, ch] - want)
+                    if c["dither"][ch] and undefined[dith_rank[ch]][b]:
+                        dev[sorted(undefined[dith_rank[ch]][b])] = 0.0          # the reference read past its table there
+                    assert dev.max() <= lim, (who, seed, b, ch, float(dev.max()), lim)
                 else:
                     lvl = max(float(np.sqrt((want ** 2).mean())), 1e-3 * scale, fuzz.FLOOR)
                     err = float(np.sqrt(((arr[:, ch] - want) ** 2).mean()))
