@@ -669,7 +669,8 @@ def _combined_engine(cls, c):
     return e
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("BFHIP_REFLOOP_SEEDS", "24"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BFHIP_REFLOOP_SEED0", "0")),
+                                        int(os.environ.get("BFHIP_REFLOOP_SEED0", "0")) + int(os.environ.get("BFHIP_REFLOOP_SEEDS", "24"))))
 def test_reference_filter_process_on_random_networks_over_random_channel_maps(hip, tmp_path, seed):
     """everything at once: filter networks with run-time control (cascades through convolve_eval,
     cross-fades, coeff -1, delayblocks) over N:1 channel maps with delays, mutes, dither and sub-sample
