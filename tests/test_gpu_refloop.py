@@ -361,7 +361,8 @@ def _channel_engine(cls, c):
     return e
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("BFHIP_REFLOOP_SEEDS", "24"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BFHIP_REFLOOP_SEED0", "0")),
+                                        int(os.environ.get("BFHIP_REFLOOP_SEED0", "0")) + int(os.environ.get("BFHIP_REFLOOP_SEEDS", "24"))))
 def test_reference_filter_process_with_shared_channels_delays_mutes_dither_subdelay(hip, tmp_path, seed):
     """bfrun.c:1128-1198, 1505-1531, 1938-2003 -- virtual channels that share a physical one are delayed
     (the reference's delay.c), muted and mixed inside filter_process(); the HP-TPDF dither of the
