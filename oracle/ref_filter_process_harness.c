@@ -90,7 +90,7 @@ main(int argc, char *argv[])
     FILE *f, *fo;
     int L, N, rs, n_ch[2], fmt[2], n_coeffs, n_filters, n_blocks, n_events, n_procs;
     int n, i, j, c, k, curbuf = 0, status = 0;
-    int in_pipe[2], out_pipe[2], f2f[BF_MAXPROCESSES][2], filter_writefd[BF_MAXPROCESSES];
+    int in_pipe[2], out_pipe[2], cb_in[2], cb_out[2], per_in, per_out, f2f[BF_MAXPROCESSES][2], filter_writefd[BF_MAXPROCESSES];
     int *fft_ch[BF_MAXPROCESSES][2], n_fft_ch[BF_MAXPROCESSES][2], cpos[2], *fproc_of;
     char toks[BF_MAXPROCESSES];
     pid_t pids[BF_MAXPROCESSES];
@@ -404,7 +404,8 @@ main(int argc, char *argv[])
         struct sample_format *sf = &dai_buffer_format[OUT]->bf[conf.virt2phys[OUT][n]].sf;
         icomm->overflow[n].max = sf->isfloat ? 1.0 : (double)((uint64_t)1 << ((sf->sbytes << 3) - 1)) - 1;
     }
-    if (pipe(mutex_pipe) == -1 || pipe(in_pipe) == -1 || pipe(out_pipe) == -1 || !writefd(mutex_pipe[1], &tok, 1)) {
+    if (pipe(mutex_pipe) == -1 || pipe(in_pipe) == -1 || pipe(out_pipe) == -1 || pipe(cb_in) == -1 || pipe(cb_out) == -1 ||
+        !writefd(mutex_pipe[1], &tok, 1)) {
         perror("pipe");
         return 2;
     }
@@ -452,6 +453,21 @@ main(int argc, char *argv[])
                     filter_writefd[i] = f2f[i][1];
                 }
             }
+            /* BFREF_CALLBACK_IO: the devices are callback ones (JACK: bfio_jack) -- the init handshake stays on
+               the blocking pipes (bfrun.c:1124, 1414), the periods are woken and reported on the callback
+               pipes (:1431, :2021) */
+            if (getenv("BFREF_CALLBACK_IO") != NULL) {
+                close(cb_in[1]);
+                close(cb_out[0]);
+                filter_process(&bfaccess, inbuf, outbuf, in_freq, out_freq,
+                               f2f[k][0], filter_writefd,
+                               in_pipe[0], cb_in[0], out_pipe[1], cb_out[1],
+                               n_fft_ch[k][IN], fft_ch[k][IN], n_fft_ch[k][OUT], fft_ch[k][OUT],
+                               conf.fproc[k].n_unique_channels[IN], conf.fproc[k].unique_channels[IN],
+                               conf.fproc[k].n_unique_channels[OUT], conf.fproc[k].unique_channels[OUT],
+                               conf.fproc[k].n_filters, conf.fproc[k].filters, k,
+                               false, false, true, true);
+            }
             filter_process(&bfaccess, inbuf, outbuf, in_freq, out_freq,
                            f2f[k][0], filter_writefd,
                            in_pipe[0], -1, out_pipe[1], -1,
@@ -467,6 +483,10 @@ main(int argc, char *argv[])
     }
     close(in_pipe[0]);
     close(out_pipe[1]);
+    close(cb_in[0]);
+    close(cb_out[1]);
+    per_in = getenv("BFREF_CALLBACK_IO") != NULL ? cb_in[1] : in_pipe[1];
+    per_out = getenv("BFREF_CALLBACK_IO") != NULL ? cb_out[0] : out_pipe[0];
 
     /* ---- the input and output processes on the other end of the pipes (bfrun.c:2480-2616) */
     if ((fo = fopen(argv[2], "wb")) == NULL) {
@@ -536,17 +556,17 @@ main(int argc, char *argv[])
            fast one from taking process 0's token is a synch_filter_processes() barrier */
         if (getenv("BFREF_STALL_PROC0") != NULL && n_procs > 1) {
             kill(pids[0], SIGSTOP);
-            if (!writefd(in_pipe[1], toks, n_procs)) {
+            if (!writefd(per_in, toks, n_procs)) {
                 return 1;
             }
             usleep((useconds_t)atoi(getenv("BFREF_STALL_PROC0")));      /* the stall, in microseconds */
             kill(pids[0], SIGCONT);
-            if (!readfd(out_pipe[0], toks, n_procs)) {
+            if (!readfd(per_out, toks, n_procs)) {
                 fprintf(stderr, "ref_filter_process: a filter process died in block %d\n", k);
                 return 1;
             }
         } else
-        if (!writefd(in_pipe[1], toks, n_procs) || !readfd(out_pipe[0], toks, n_procs)) {
+        if (!writefd(per_in, toks, n_procs) || !readfd(per_out, toks, n_procs)) {
             fprintf(stderr, "ref_filter_process: a filter process died in block %d\n", k);
             return 1;
         }
@@ -561,6 +581,7 @@ main(int argc, char *argv[])
     /* closing the wake pipe ends the filter process the way the reference ends: its read fails and
        it calls bf_exit() */
     close(in_pipe[1]);
+    close(cb_in[1]);
     for (k = 0; k < n_procs; k++) {
         waitpid(pids[k], &status, 0);
     }

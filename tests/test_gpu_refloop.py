@@ -748,3 +748,24 @@ def test_reference_filter_process_on_random_networks_over_random_channel_maps(hi
             continue
         many, _, _ = _run_host(EXE_PATCHED, tmp_path, "p%d" % n_proc, hspec, blocks, events, f_owner, env=env)
         assert many == fused, (seed, n_proc, f_owner)
+
+
+def test_two_periods_in_flight_are_opt_in_and_for_blocking_io_only(hip, tmp_path):
+    """The patched host keeps the reference's I/O delay (brutefir.html:839) by default; BFHIP_TWO_PERIODS=1
+    trades one more period of delay for the overlap of copies and kernels: the same samples, one block
+    later.  With callback I/O (JACK) the switch is ignored: the callback must get its period back."""
+    for exe in (EXE, EXE_PATCHED):
+        if not os.path.exists(exe):
+            pytest.fail("%s is missing (built from the reference's bfrun.c in the build container)" % exe)
+    spec, n_blocks, events = fuzz._network(9003)
+    spec = dict(spec, outfmt="S24_4LE")
+    blocks = cases.raw_blocks(3, n_blocks, spec["L"], spec["n_in"], spec["infmt"], amplitude=0.2)
+    blk_bytes = spec["L"] * spec["n_out"] * 4
+    normal, _, _ = _run_host(EXE_PATCHED, tmp_path, "normal", spec, blocks, events)
+    late, _, _ = _run_host(EXE_PATCHED, tmp_path, "late", spec, blocks, events, env={"BFHIP_TWO_PERIODS": "1"})
+    assert late[blk_bytes:] == normal[:-blk_bytes] and late != normal
+    cb, _, _ = _run_host(EXE_PATCHED, tmp_path, "cb", spec, blocks, events, env={"BFREF_CALLBACK_IO": "1", "BFHIP_TWO_PERIODS": "1"})
+    assert cb == normal
+    plain_cb, _, _ = _run_host(EXE, tmp_path, "plain_cb", spec, blocks, events, env={"BFREF_CALLBACK_IO": "1"})
+    plain, _, _ = _run_host(EXE, tmp_path, "plain", spec, blocks, events)
+    assert plain_cb == plain                     # the reference's own loop: the same bytes on either kind of pipe
