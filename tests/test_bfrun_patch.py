@@ -125,3 +125,14 @@ def test_reference_filter_process_binary_is_built_without_placeholders():
     assert not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "patched"))
     recipe = open(os.path.join(ROOT, "oracle", "Makefile")).read()
     assert "defsym" not in recipe.split("$(FPROC):")[1].split("endif")[0]
+
+
+def test_the_fused_period_keeps_one_barrier_between_the_filter_processes():
+    """all filter processes wake on one pipe (bfrun.c:833, 2488: n_processes tokens a period); the fused
+    path must keep a synch_filter_processes() in front of its period or a fast process takes two tokens
+    (tests/test_gpu_refloop.py::test_filter_processes_keep_step_on_their_shared_wake_pipe shows it on the GPU)"""
+    diff = open(os.path.join(ROOT, "patches", "bfrun-bfhip.diff")).read()
+    added = [ln[1:].strip() for ln in diff.splitlines() if ln.startswith("+") and not ln.startswith("+++")]
+    i_bar = added.index("synch_filter_processes(filter_readfd, filter_writefd, process_index);")
+    i_per = next(i for i, ln in enumerate(added) if ln.startswith("bfhip_period(icomm_fctrl"))
+    assert i_bar < i_per and i_per - i_bar <= 2
