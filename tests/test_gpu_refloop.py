@@ -405,14 +405,19 @@ def test_reference_filter_process_with_shared_channels_delays_mutes_dither_subde
                 # HP-TPDF quantiser feeds its error back with coefficients {1, -1} (dither_funs.h:20-27), so
                 # one rounding decision that falls the other way moves the next two samples by a count
                 # each way on top of their own rounding
-                lim = 4.0 if c["outfmt"] == "S24_4LE" else 1.0
+                # (... plus, on 24-bit outputs of a float32 engine, the float tolerance in counts: a sub-sample FIR,
+                # a mix and the transforms' round trips at a level of a million counts -- seed 3187: 5 counts)
+                full = 32768.0 if c["outfmt"] == "S16_LE" else 8388608.0
                 dith = np.asarray(c["dither"], bool)
                 dev = np.abs(arr - ref[b])
                 for k, pch in enumerate(np.nonzero(dith)[0]):         # (where the reference reads past its dither table)
                     if undefined[k][b]:
                         dev[sorted(undefined[k][b]), pch] = 0.0
                 d = dev.max(axis=0)
-                assert (d[~dith] <= lim).all() and (d[dith] <= 2.0).all(), (who, seed, b, d)
+                for pch in range(n_phys_out):
+                    lvl = max(float(np.sqrt((ref[b][:, pch] ** 2).mean())), 1e-3 * scale, fuzz.FLOOR * full)
+                    lim = (2.0 if dith[pch] else 1.0) + 16 * tol * lvl
+                    assert d[pch] <= lim, (who, seed, b, pch, float(d[pch]), lim)
                 continue
             else:
                 for ch in range(n_phys_out):
