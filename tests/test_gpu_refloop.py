@@ -211,7 +211,8 @@ def _run_host(exe, tmp_path, tag, spec, blocks, events, f_owner=None, env=None):
     return open(out, "rb").read(), [ln for ln in r.stdout.splitlines() if ln.startswith("output ")], r.stderr
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("BFHIP_REFLOOP_SEEDS", "24")) // 2))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BFHIP_REFLOOP_SEED0", "0")),
+                                        int(os.environ.get("BFHIP_REFLOOP_SEED0", "0")) + int(os.environ.get("BFHIP_REFLOOP_SEEDS", "24")) // 2))
 def test_the_patched_filter_process_runs_and_its_processes_agree(hip, tmp_path, seed):
     """patches/bfrun-bfhip.diff applied to the reference's bfrun.c and RUN (oracle/_ref/ref_filter_process_bfhip,
     -DBF_HAVE_BFHIP): the patched filter_process() takes the fused path -- bfhip_setup() builds the engine

@@ -15,7 +15,7 @@ LOG=gpurun_out/soak/${FAMILY}_${SEED0}.txt
 case "$FAMILY" in
   combined) K="random_networks_over"; FILES=tests/test_gpu_refloop.py ;;
   channels) K="shared_channels"; FILES=tests/test_gpu_refloop.py ;;
-  networks) K="over_the_product or patched_filter_process"; FILES=tests/test_gpu_refloop.py ;;      # (no seed offset: 0 .. N)
+  networks) K="over_the_product or patched_filter_process"; FILES=tests/test_gpu_refloop.py ;;      # (the seed offset moves the patched multi-process cases only)
   engine)   K=""; FILES="tests/test_gpu_fuzz.py tests/test_gpu_shards.py" ;;
   *) echo "unknown family $FAMILY"; exit 2 ;;
 esac
