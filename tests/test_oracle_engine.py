@@ -260,3 +260,35 @@ def test_delay_cascade_crossfade_network_against_numpy(rs, tol):
     for b in (sw - 1, sw, sw + 1):
         s = slice(b * L, (b + 1) * L)
         assert cases.rel_rms(y[s, 0], want[s, 0]) <= 2 * tol, b
+
+
+def test_an_input_muted_from_the_start_keeps_the_delay_it_was_configured_with():
+    """the delay buffer of a shared input exists from the start (bfrun.c:1128-1166), muted or not, with
+    the delay configured then; a fixed delay (maxdelay -1) is not moved by set_delay while the channel
+    is muted either (delay.c:289).  The oracle once built the buffer at the first unmuted block with
+    the delay of THAT moment -- the reference and the engine disagreed with it
+    (tests/test_gpu_refloop.py, seed 323)."""
+    L, N = 64, 2
+    e = bo.Engine(L, N, 8, 2, 1)
+    e.map_channels(0, [0, 0])               # both virtual inputs from physical input 0
+    e.set_interleaved_phys(0, "FLOAT64_LE", 1)
+    e.set_interleaved(1, "FLOAT64_LE")
+    e.add_filter(in_ch=[0], out_ch=[0], coeff=-1)
+    e.add_filter(in_ch=[1], out_ch=[0], coeff=-1, in_scale=[0.0])
+    e.set_delay(0, 0, 100); e.set_maxdelay(0, 0, -1)
+    e.set_mute(0, 0, 1)
+    nblk = 10
+    x = np.random.default_rng(9).standard_normal((nblk * L, 1))
+    y = []
+    for b in range(nblk):
+        if b == 2:
+            e.set_delay(0, 0, 30)           # while muted, on a fixed delay: nothing
+        if b == 4:
+            e.set_mute(0, 0, 0)
+        st, raw = e.block(x[b * L:(b + 1) * L])
+        assert st == 0
+        y.append(raw.view(np.float64).reshape(L))
+    y = np.concatenate(y)
+    heard = x[4 * L:, 0]                    # what the delay line has seen: the blocks since the unmute
+    want = np.concatenate([np.zeros(4 * L), np.zeros(100), heard[:len(heard) - 100]])
+    assert np.abs(y - want).max() < 1e-12
