@@ -292,3 +292,36 @@ def test_an_input_muted_from_the_start_keeps_the_delay_it_was_configured_with():
     heard = x[4 * L:, 0]                    # what the delay line has seen: the blocks since the unmute
     want = np.concatenate([np.zeros(4 * L), np.zeros(100), heard[:len(heard) - 100]])
     assert np.abs(y - want).max() < 1e-12
+
+
+def test_fixed_delays_beside_a_subsample_filter_in_the_oracle():
+    """maxdelay -1 on channels that share a physical one, beside a sub-sample filter on the same side: the
+    reference's set-up overruns its delay buffer there (bfrun.c:1152-1162 + delay.c:357-374, DESIGN 7);
+    the oracle's (and the engine's: tests/test_gpu_features.py) defined answer is delay + sdf_length,
+    fixed -- an impulse comes out where that says"""
+    L, N, half = 64, 2, 15
+    e = bo.Engine(L, N, 4, 3, 3)
+    e.map_channels(0, [0, 0, 1])
+    e.map_channels(1, [0, 0, 1])
+    e.set_interleaved_phys(0, "FLOAT_LE", 2)
+    e.set_interleaved_phys(1, "FLOAT_LE", 2)
+    e.enable_subdelay(half)
+    e.set_subdelay(0, 0, 0)
+    e.set_subdelay(1, 0, 0)
+    for io in range(2):
+        e.set_maxdelay(io, 1, -1); e.set_delay(io, 1, 700 if io == 0 else 20)
+        e.set_maxdelay(io, 0, 40); e.set_delay(io, 0, 90)
+    e.add_filter(in_ch=[1], out_ch=[1], coeff=-1)
+    e.add_filter(in_ch=[0], out_ch=[0], coeff=-1, in_scale=[0.0])
+    e.add_filter(in_ch=[2], out_ch=[2], coeff=-1)
+    x = np.zeros((16 * L, 2), np.float32)
+    x[5, 0] = 1.0
+    got = []
+    for b in range(16):
+        if b == 3:
+            e.set_delay(0, 1, 10)               # refused: the delay is fixed
+        st, raw = e.block(x[b * L:(b + 1) * L])
+        assert st == 0
+        got.append(raw.view(np.float32).reshape(L, 2)[:, 0])
+    y = np.concatenate(got)
+    assert int(np.argmax(np.abs(y))) == 5 + (700 + half) + (20 + half) and abs(float(y.max()) - 1.0) < 1e-5
